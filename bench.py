@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native MDR hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+metric  : queries/sec of the 2-hop beam-search retrieval loop (BASELINE.json) over a synthetic
+          5M x 768 fp32 index, 100-question batches, beam=1 topk=1 (BASELINE configs[2] shape).
+step    : one batch of 100 questions through hop-1 encode -> MIPS -> hop-2 encode -> MIPS -> path rank
+          (scripts/eval/eval_mhop_retrieval.py:142-206 of the reference), inputs resident in HBM.
+N > 1   : launched by torch.distributed.run, one rank per GPU; the corpus is row-sharded, questions are
+          split across ranks for the encoder, per-shard top-k lists are exchanged with one RCCL
+          all_gather per hop (strong scaling of the fixed 5M-row index).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = MIPS stream kernel, HBM-bound) and
+`cpu_baseline` (oracle/flat_ip_oracle.c, the FAISS-equivalent CPU path, on a bounded row sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CHUNK_ROWS = 250_000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=5_000_000, help="corpus rows (global)")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=100, help="questions per step")
+    ap.add_argument("--beam", type=int, default=1)
+    ap.add_argument("--topk", type=int, default=1)
+    ap.add_argument("--max-q-len", type=int, default=70)
+    ap.add_argument("--max-q-sp-len", type=int, default=350)
+    ap.add_argument("--no-encoder", action="store_true", help="MIPS-only step (query embeddings synthetic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--pmc-traffic", type=float, default=None, help="HBM bytes per launch from a rocprofv3 --pmc pass")
+    return ap.parse_args()
+
+
+def corpus_chunk(seed, c, rows, dim, device):
+    g = torch.Generator(device=device).manual_seed(seed * 1_000_003 + c)
+    return torch.randn((rows, dim), generator=g, device=device, dtype=torch.float32)
+
+
+def build_shard(index, lo, hi, dim, device, keep_rows=None):
+    """Rows [lo, hi) of the global synthetic matrix (chunk-keyed RNG: any sharding reproduces it)."""
+    kept = []
+    c0, c1 = lo // CHUNK_ROWS, (hi - 1) // CHUNK_ROWS if hi > lo else -1
+    for c in range(c0, c1 + 1):
+        base = c * CHUNK_ROWS
+        blk = corpus_chunk(0, c, CHUNK_ROWS, dim, device)
+        a, b = max(lo, base) - base, min(hi, base + CHUNK_ROWS) - base
+        index.add(blk[a:b])
+        if keep_rows is not None:
+            sel = (keep_rows >= base + a) & (keep_rows < base + b)
+            kept.append((sel, blk[(keep_rows[sel] - base)].clone()))
+        del blk
+    return kept
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)  # "nccl" == RCCL on ROCm
+
+    from multihop_dense_retrieval_amd import index as mdr_index
+    from multihop_dense_retrieval_amd import mhop
+
+    N, d, B = args.rows, args.dim, args.batch
+    t0 = time.time()
+    if world > 1:
+        sidx = mdr_index.ShardedIndexFlatIP(d, N)
+        lo, hi = sidx.lo, sidx.hi
+        local = sidx.local
+    else:
+        local = mdr_index.IndexFlatIP(d, device=device)
+        sidx = local
+        lo, hi = 0, N
+    local.reserve(hi - lo)
+    # planted hop-1 answers make the run self-checking at full size: question i's best row is p_i
+    planted = (torch.arange(B, device=device, dtype=torch.int64) * 48_611 + 17) % N
+    kept = build_shard(local, lo, hi, d, device, keep_rows=planted)
+    rows_sum = torch.zeros((B, d), device=device)
+    for sel, rows in kept:
+        rows_sum[sel] += rows
+    if world > 1:
+        dist.all_reduce(rows_sum)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+
+    pipe = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device,
+                                max_q_len=args.max_q_len, max_q_sp_len=args.max_q_sp_len,
+                                use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank, world=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pipe.step()
+    barrier()
+    pipe.reset_kernel_timers()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipe.step()
+    barrier()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # self-check at full size: MIPS-only mode plants the hop-1 answers
+    ok = pipe.self_check(out, planted)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    qps = B * args.steps / elapsed
+    search_ms = pipe.search_kernel_ms()  # HIP-event average over every timed search call (rank-local)
+    stream_bytes = local.stream_bytes()
+    achieved = stream_bytes / (search_ms * 1e-3) / 1e9 if search_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": local.last_kernel(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.pmc_traffic,
+                "algorithmic_bytes_per_launch": stream_bytes, "avg_launch_ms": round(search_ms, 4),
+                "launches_timed": pipe.search_calls_timed()}
+
+    result = {
+        "metric": "queries/sec (2-hop, beam-size x topk) over 5Mx768 index",
+        "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 (index stored as fp16 hi/lo pairs, fp32 accumulate); encoder f16 MFMA / f32 accumulate",
+        "data": "synthetic",
+        "config": {"workload": f"synthetic {N}x{d} fp32 corpus, {B}-question batches, 2-hop beam={args.beam} topk={args.topk}"
+                               f"{' , MIPS-only (no encoder)' if not pipe.use_encoder else ', RoBERTa-base encoder (random init)'}",
+                   "rows": N, "dim": d, "batch": B, "beam": args.beam, "topk": args.topk, "shards": world,
+                   "encoder": pipe.encoder_desc(), "index_build_s": round(build_s, 2)},
+        "roofline": roofline,
+        "self_check": ok,
+        "stage_ms": pipe.stage_ms(),
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, device)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, device):
+    """FAISS-equivalent CPU path (oracle/flat_ip_oracle.c, kind 'port') on the GPU box's host cores,
+    bounded to ~args.cpu_seconds: the two searches of one 100-question step over a row SAMPLE of the same
+    synthetic corpus, linearly extrapolated to the full row count (flat search is linear in rows)."""
+    import ctypes
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(so)
+    f = lib.mdr_oracle_flat_ip_search
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+                  ctypes.c_void_p, ctypes.c_int]
+    lib.mdr_oracle_num_threads.restype = ctypes.c_int
+    cores = int(lib.mdr_oracle_num_threads())
+    d, B, k = args.dim, args.batch, args.beam
+    q = corpus_chunk(1, 0, B, d, device).cpu().numpy()
+    D = np.empty((B, k), np.float32)
+    I = np.empty((B, k), np.int64)
+
+    def run(xb):
+        t = time.perf_counter()
+        rc = f(q.ctypes.data, B, xb.ctypes.data, xb.shape[0], d, k, D.ctypes.data, I.ctypes.data, 0)
+        assert rc == 0
+        return time.perf_counter() - t
+
+    probe = corpus_chunk(0, 0, 100_000, d, device).cpu().numpy()
+    run(probe)
+    rate = 100_000 / run(probe)  # rows/s for one search call
+    sample_rows = int(min(args.rows, max(100_000, rate * args.cpu_seconds / 2)))
+    sample_rows = min(sample_rows, 4_000_000)  # host RAM bound: 12 GB
+    nchunk = -(-sample_rows // CHUNK_ROWS)
+    xb = np.concatenate([corpus_chunk(0, c, CHUNK_ROWS, d, device).cpu().numpy() for c in range(nchunk)])[:sample_rows]
+    t = run(xb) + run(xb)  # hop 1 + hop 2
+    step_s = t * (args.rows / sample_rows)
+    return {"value": round(B / step_s, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"2 flat-IP searches (hop 1 + hop 2) of {B} queries, k={k}, over the first {sample_rows} rows of the same "
+                      f"synthetic corpus in {t:.2f} s, extrapolated linearly to {args.rows} rows; MIPS only (the reference's "
+                      f"encoder runs on the GPU in the reference too)",
+            "impl": "oracle/flat_ip_oracle.c (restatement of faiss IndexFlatIP::search, OpenMP)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/*
+ * include/mdr_hip.h -- C ABI of libmdrhip.so, the MI355X (gfx950) implementation of the
+ * iterative-retrieval hot path of facebookresearch/multihop_dense_retrieval.
+ *
+ * The reference has no FFI of its own (it is pure Python). Each entry point below
+ * replaces the third-party native call the reference makes at the cited line, with plain C types
+ * only (no torch / numpy / faiss types), so that any host language can bind it. INTEGRATION.md shows
+ * the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, negative = error class (MDR_E_*); the message of the last
+ *     error on the calling thread is mdr_last_error(). Nothing throws, nothing calls exit().
+ *   - pointers named *_dev are DEVICE pointers on the handle's device; *_host are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). All work is enqueued
+ *     asynchronously on it; no entry point synchronises the device except mdr_index_add with a host
+ *     source (which must finish reading the host buffer before it returns).
+ *   - the caller owns every buffer it passes (queries, results, workspace); a handle owns only its
+ *     own storage (corpus shard, encoder weight copies).
+ *   - one handle per (process, device); calls on one handle are not re-entrant.
+ */
+#ifndef MDR_HIP_H
+#define MDR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDR_OK 0
+#define MDR_E_INVALID (-1)  /* bad argument (k < 1, k > MDR_KMAX, nq < 0, d unsupported, NULL ...) */
+#define MDR_E_HIP (-2)      /* a HIP runtime call failed; mdr_last_error() carries hipGetErrorString */
+#define MDR_E_RANGE (-3)    /* value not representable in the index storage (|x| > 32768 for F32X2H) */
+#define MDR_E_WORKSPACE (-4) /* workspace too small: call the matching *_workspace_bytes first */
+#define MDR_E_STATE (-5)    /* handle in the wrong state (e.g. search on an empty encoder) */
+
+#define MDR_KMAX 2048       /* largest k accepted by mdr_index_search */
+
+/* element types of caller-side arrays */
+#define MDR_DT_F32 0
+#define MDR_DT_BF16 1
+#define MDR_DT_F16 2
+
+/* index storage formats */
+#define MDR_STORE_F32X2H 0  /* fp32-accurate: each element kept as an fp16 (hi, lo) pair = 4 bytes  */
+#define MDR_STORE_BF16 1    /* 2 bytes per element, scores exact w.r.t. the bf16-rounded corpus     */
+
+const char* mdr_last_error(void);
+const char* mdr_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flat inner-product index  ==  faiss.IndexFlatIP as used by the reference:
+ *   index = faiss.IndexFlatIP(d)          /root/reference/scripts/eval/eval_mhop_retrieval.py:121
+ *   index.add(xb)                         /root/reference/scripts/eval/eval_mhop_retrieval.py:122
+ *   index_cpu_to_gpu(res, 6, index)       /root/reference/scripts/eval/eval_mhop_retrieval.py:123-125
+ *   D, I = index.search(q, beam)          /root/reference/scripts/eval/eval_mhop_retrieval.py:155,179
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mdr_index mdr_index;
+
+/* d: vector dimension (multiple of 32, <= 1024). storage: MDR_STORE_*. device: HIP device ordinal. */
+int mdr_index_create(int d, int storage, int device, mdr_index** out);
+int mdr_index_free(mdr_index* h);
+
+/* Pre-size the shard (rows). Optional: add() grows geometrically, but reserving avoids the copy. */
+int mdr_index_reserve(mdr_index* h, int64_t n_rows);
+
+/* Append n rows of `d` elements (C-contiguous, element type src_dtype) from a host or device buffer.
+ * Rows receive consecutive ids starting at mdr_index_ntotal(). (IndexFlatIP.add) */
+int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int rows_on_device, void* stream);
+
+int64_t mdr_index_ntotal(const mdr_index* h);
+int mdr_index_dim(const mdr_index* h);
+/* bytes of HBM one search call streams for the corpus (= ntotal_padded * d * bytes/elem) */
+int64_t mdr_index_stream_bytes(const mdr_index* h);
+
+/* Workspace one search call needs (device memory, 256-byte aligned, contents don't persist). */
+size_t mdr_index_search_workspace_bytes(const mdr_index* h, int nq, int k);
+
+/* Top-k rows by inner product, best first (IndexFlatIP.search):
+ *   q_dev  f32 [nq, d] C-contiguous     D_dev f32 [nq, k] descending     I_dev i64 [nq, k]
+ * Ties are ordered by ascending row id (FAISS keeps the first-seen = lowest id among equal scores).
+ * When the index holds fewer than k rows the tail is D = -FLT_MAX, I = -1 (FAISS behaviour).
+ * id_offset is added to every returned id (global id of this shard's row 0). */
+int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_dev, int64_t* I_dev,
+                     int64_t id_offset, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Test hook: force a kernel variant (0 = auto, 1 = generic fp32 reference kernel, 2 = MFMA stream). */
+int mdr_index_set_variant(mdr_index* h, int variant);
+/* Name of the kernel the last search dispatched to (for rocprof matching); static storage. */
+const char* mdr_index_last_kernel(const mdr_index* h);
+
+/* ------------------------------------------------------------------------------------------------
+ * k-way merge of per-shard result lists (what every rank runs after the RCCL all-gather that
+ * BASELINE.json's north_star adds in front of the hop-2 re-query; the reference itself is
+ * single-index, eval_mhop_retrieval.py:155):
+ *   D_parts f32 [nparts, nq, k], I_parts i64 [nparts, nq, k]  ->  D f32 [nq, k], I i64 [nq, k]
+ * Same order rule as search: score descending, then id ascending; entries with I < 0 are padding.
+ * ---------------------------------------------------------------------------------------------- */
+int mdr_topk_merge(const float* D_parts_dev, const int64_t* I_parts_dev, int nparts, int nq, int k,
+                   float* D_dev, int64_t* I_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RoBERTa-base encoder forward + CLS projection  ==
+ *   RobertaRetriever.encode_q / encode_seq   /root/reference/mdr/retrieval/models/mhop_retriever.py:23-26,40-41
+ *   RobertaCtxEncoder.forward                /root/reference/mdr/retrieval/models/retriever.py:186-190
+ * i.e. project(encoder(input_ids, mask)[0][:, 0, :]) with HF RobertaModel semantics, fp16 tensor-core
+ * GEMMs with fp32 accumulation and fp32 LayerNorm / softmax / GELU (the apex-O1 numerics the
+ * reference runs under, eval_mhop_retrieval.py:88-89).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mdr_encoder mdr_encoder;
+
+typedef struct mdr_encoder_config {
+    int vocab, hidden, layers, heads, ffn, max_pos, pad_id;
+    float ln_eps;
+} mdr_encoder_config;
+
+/* One fp32 tensor of the q_encoder.pt schema, Linear weights [out, in]. */
+typedef struct mdr_tensor {
+    const char* name;   /* state-dict key without any "module." prefix                      */
+    const float* data;  /* host or device pointer (see weights_on_device), C-contiguous fp32 */
+    int64_t numel;
+} mdr_tensor;
+
+/* Copies (and converts to fp16 where the GEMMs want it) every tensor it needs; unknown names are
+ * ignored (load_saved(exact=False), mdr/retrieval/utils/utils.py:19), a missing one is MDR_E_INVALID
+ * naming the key (strict load_state_dict raises, utils.py:21). encoder.pooler.* is never required. */
+int mdr_encoder_create(const mdr_encoder_config* cfg, const mdr_tensor* tensors, int n_tensors,
+                       int weights_on_device, int device, void* stream, mdr_encoder** out);
+int mdr_encoder_free(mdr_encoder* h);
+
+size_t mdr_encoder_workspace_bytes(const mdr_encoder* h, int batch, int seq_len);
+
+/* ids_dev / mask_dev: int64 [batch, seq_len] (right-padded; mask 1 = token, 0 = pad);
+ * out_dev: f32 [batch, hidden]. Padded positions are skipped, which is result-identical for the
+ * CLS embedding. */
+int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* mask_dev, int batch, int seq_len,
+                        float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDR_HIP_H */

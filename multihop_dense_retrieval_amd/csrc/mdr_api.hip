@@ -1,0 +1,27 @@
+// csrc/mdr_api.hip -- error state and version of libmdrhip.so (include/mdr_hip.h).
+#include <cstdarg>
+#include <cstdio>
+
+#include "mdr_common.h"
+
+namespace mdr {
+
+char* last_error_buf() {
+    static thread_local char buf[512] = "";
+    return buf;
+}
+
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+}  // namespace mdr
+
+extern "C" {
+const char* mdr_last_error(void) { return mdr::last_error_buf(); }
+const char* mdr_version(void) { return "mdr-hip 0.1 (gfx950)"; }
+}

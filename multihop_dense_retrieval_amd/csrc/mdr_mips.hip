@@ -1,0 +1,852 @@
+// csrc/mdr_mips.hip -- brute-force maximum-inner-product search for gfx950 (MI355X).
+//
+// Replaces faiss.IndexFlatIP.{add,search} as the reference uses them
+// (/root/reference/scripts/eval/eval_mhop_retrieval.py:121-122,155,179). See DESIGN.md §3.
+//
+// Storage (MDR_STORE_F32X2H). Every fp32 element x is kept as an fp16 pair
+//     hi = fp16(x)            lo = fp16((x - hi) * 2^11)          x ~= hi + lo * 2^-11   (22-bit mantissa)
+// = 4 bytes per element, the same HBM bytes as fp32, laid out in MFMA-operand order so that the
+// search kernel's HBM->LDS DMA and its LDS->register reads are both perfectly linear:
+//     row-block rb (16 rows) -> k-block kb (32 columns) -> plane {hi,lo} -> 1 KiB fragment block
+//     fragment block: lane l = (row & 15) + 16 * ((col & 31) >> 3) holds 8 consecutive columns (16 B)
+// which is exactly the A/B operand layout of v_mfma_f32_16x16x32_f16.
+//
+// Search, nq <= 128 per pass ("stream" kernel): one 512-thread workgroup per CU, persistent over
+// row-blocks. Wave w keeps the (hi, lo) fragments of queries 16w..16w+15 for ALL of K in registers
+// (2 * NKB * 4 VGPRs), the corpus streams HBM -> LDS (global_load_lds, 3-deep ring of 1 row-block
+// each) -> every wave's MFMA A operand. Three fp16 MFMAs per (row-block, k-block) give an
+// fp32-accurate score:   q.x ~= qh.xh + (qh.xl + ql.xh) * 2^-11     (ql.xl ~ 2^-22 dropped)
+// top-1 lives in two registers per lane; top-k (k <= 128) in per-wave candidate lists with a
+// running threshold. The [nq, N] score matrix is never materialised.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstring>
+#include <new>
+
+#include "mdr_common.h"
+
+namespace mdr {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+constexpr int kRowBlock = 16;          // corpus rows per MFMA tile
+constexpr int kFragBytes = 1024;       // one 16x32 fp16 fragment block
+constexpr float kLoScale = 2048.0f;    // 2^11
+constexpr float kLoInv = 1.0f / 2048.0f;
+constexpr int kStreamQ = 128;          // queries per pass of the stream kernel (8 waves x 16)
+constexpr int kStreamCap = 256;        // candidate slots per (workgroup, query) in the stream kernel
+constexpr int kGenericQ = 64;          // queries per pass of the generic kernel (4 waves x 16)
+constexpr int kGenericCap = 2048;      // >= 2 * MDR_KMAX'
+constexpr int kKMax = 1024;            // effective k limit (<= MDR_KMAX)
+constexpr int kMergeLds = 6144;        // keys the merge kernel can hold in LDS (48 KiB)
+
+// ---- order-preserving packing: (score desc, row asc)  <=>  key desc -------------------------------
+__host__ __device__ inline unsigned ord32(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float unord32(unsigned u) {
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__host__ __device__ inline u64 make_key(float s, unsigned row) { return ((u64)ord32(s) << 32) | (u64)(0xFFFFFFFFu - row); }
+__host__ __device__ inline float key_score(u64 k) { return unord32((unsigned)(k >> 32)); }
+__host__ __device__ inline unsigned key_row(u64 k) { return 0xFFFFFFFFu - (unsigned)k; }
+
+// ---- fragment-tiled addressing ---------------------------------------------------------------------
+__host__ __device__ inline size_t frag_offset(long long row, int col, int nkb) {
+    long long rb = row >> 4;
+    int rr = (int)(row & 15), kb = col >> 5, g = (col & 31) >> 3, j = col & 7;
+    return (size_t)rb * ((size_t)nkb * 2 * kFragBytes) + (size_t)kb * 2 * kFragBytes + (size_t)(rr + 16 * g) * 16 + (size_t)j * 2;
+}
+
+// ---- conversion: row-major {f32,bf16,f16} -> fragment-tiled (hi, lo) fp16 -------------------------
+template <typename T>
+__device__ inline float load_as_f32(const T* p);
+template <>
+__device__ inline float load_as_f32<float>(const float* p) { return *p; }
+template <>
+__device__ inline float load_as_f32<unsigned short>(const unsigned short* p) {  // bf16 bits
+    unsigned u = ((unsigned)*p) << 16;
+    return __uint_as_float(u);
+}
+template <>
+__device__ inline float load_as_f32<_Float16>(const _Float16* p) { return (float)*p; }
+
+// one thread per (row, 8-column group); rows [n_valid, n_total) are written as zeros (padding)
+template <typename T>
+__global__ void __launch_bounds__(256) convert_to_frag_kernel(const T* __restrict__ src, long long n_valid, long long n_total,
+                                                              int d, long long row0, char* __restrict__ dst, int* __restrict__ flags) {
+    const int gpr = d >> 3;
+    const int nkb = d >> 5;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long r = idx / gpr;
+    int gi = (int)(idx - r * gpr);
+    if (r >= n_total) return;
+    half8 h, l;
+    bool bad = false;
+    if (r < n_valid) {
+        const T* p = src + r * (long long)d + gi * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = load_as_f32<T>(p + j);
+            if (!(fabsf(x) <= 32768.0f)) bad = true;
+            _Float16 hh = (_Float16)x;
+            float res = x - (float)hh;
+            h[j] = hh;
+            l[j] = (_Float16)(res * kLoScale);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { h[j] = (_Float16)0.f; l[j] = (_Float16)0.f; }
+    }
+    if (bad) atomicOr(flags, 1);
+    size_t off = frag_offset(row0 + r, gi * 8, nkb);
+    *(half8*)(dst + off) = h;
+    *(half8*)(dst + off + kFragBytes) = l;
+}
+
+// ---- wave-level candidate list maintenance -----------------------------------------------------------
+__device__ inline u64 load_key_l2(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Keep the k largest of list[0..c) (unique 64-bit keys), compacted to the front. Whole wave calls it
+// with identical arguments. Returns the k-th largest key (0 if c < k). E*64 >= c.
+template <int E>
+__device__ inline u64 wave_select_topk(u64* list, int c, int k, int lane, int* new_count) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's appends have reached L2
+    u64 key[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int idx = e * 64 + lane;
+        key[e] = idx < c ? load_key_l2(list + idx) : 0ull;
+    }
+    if (c < k) { *new_count = c; return 0ull; }
+    u64 t = 0ull;
+    for (int bit = 63; bit >= 0; --bit) {
+        u64 cand = t | (1ull << bit);
+        int n = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) n += __popcll(__ballot(key[e] >= cand));
+        if (n >= k) t = cand;
+    }
+    // t is now the k-th largest key: exactly k keys are >= t
+    int base = 0;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        bool p = key[e] >= t;
+        u64 m = __ballot(p);
+        if (p) list[base + __popcll(m & lt)] = key[e];
+        base += __popcll(m);
+    }
+    *new_count = base;
+    return t;
+}
+
+// Per-wave bookkeeping after a row-block: prune every list of this wave that could overflow on the
+// next row-block (16 appends per query at most). cnt[] lives in LDS, one int per query of the wave.
+template <int E, int CAP>
+__device__ inline void wave_prune_if_needed(u64* wave_lists /* [16][CAP] */, int* wave_cnt /* LDS [16] */, int k, int lane,
+                                            float& tau, bool force, u64* kth_out /* [16] or null */) {
+    int c = wave_cnt[lane & 15];
+    bool need = force ? true : (c > CAP - 16);
+    unsigned m = (unsigned)(__ballot(need) & 0xFFFFull);  // lanes 0..15 <-> the wave's 16 queries
+    while (m) {
+        int qi = __builtin_ctz(m);
+        m &= m - 1;
+        int cq = __shfl(c, qi);
+        int nc;
+        u64 t = wave_select_topk<E>(wave_lists + (size_t)qi * CAP, cq, k, lane, &nc);
+        if ((lane & 15) == qi) {
+            if (t) tau = key_score(t);
+            if (lane == qi) {
+                wave_cnt[qi] = nc;
+                if (kth_out) kth_out[qi] = t;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void consider(float s, unsigned row, bool valid, float tau, u64* my_list, int* my_cnt) {
+    if (valid && s >= tau) {
+        int pos = atomicAdd(my_cnt, 1);  // LDS atomic
+        my_list[pos] = make_key(s, row);
+    }
+}
+
+// ---- the stream kernel -------------------------------------------------------------------------------
+#define MDR_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define MDR_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int NKB>
+__device__ __forceinline__ void issue_row_block(const char* __restrict__ X, int rb, char* slot, int wave, int lane) {
+    constexpr int CPW = NKB / 4;  // 1 KiB pieces per wave: 2*NKB pieces over 8 waves
+    const char* g = X + (size_t)rb * ((size_t)NKB * 2 * kFragBytes) + (size_t)(wave * CPW) * kFragBytes + lane * 16;
+    char* l = slot + wave * CPW * kFragBytes;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) __builtin_amdgcn_global_load_lds(MDR_GPTR(g + c * kFragBytes), MDR_LPTR(l + c * kFragBytes), 16, 0, 0);
+}
+
+template <int NKB, int KMODE>  // KMODE 0: k == 1 (register argmax)   1: 2 <= k <= 128 (candidate lists)
+__global__ void __launch_bounds__(512, 2)
+mips_stream_kernel(const char* __restrict__ X, long long n_rows, int n_rb, const char* __restrict__ Qf, int nq,
+                   u64* __restrict__ best, u64* __restrict__ cand, int* __restrict__ cand_cnt, u64* __restrict__ cand_kth, int k) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int RB_BYTES = NKB * 2 * kFragBytes;
+    constexpr int CPW = NKB / 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = gridDim.x, b = blockIdx.x;
+    const int n_my = (n_rb - b + G - 1) / G;
+    int* lds_cnt = (int*)(lds + 3 * RB_BYTES);  // [128] (KMODE 1 only)
+
+    if (KMODE == 1) {
+        if (threadIdx.x < kStreamQ) lds_cnt[threadIdx.x] = 0;
+    }
+
+    // start the corpus stream before anything else
+    if (n_my > 0) issue_row_block<NKB>(X, b, lds, wave, lane);
+    if (n_my > 1) issue_row_block<NKB>(X, b + G, lds + RB_BYTES, wave, lane);
+
+    // this wave's queries: B operand fragments for all of K, resident for the whole kernel
+    const bool wave_active = wave * 16 < nq;
+    half8 qh[NKB], ql[NKB];
+    {
+        const char* qp = Qf + (size_t)wave * RB_BYTES + lane * 16;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            qh[kb] = *(const half8*)(qp + kb * 2 * kFragBytes);
+            ql[kb] = *(const half8*)(qp + kb * 2 * kFragBytes + kFragBytes);
+        }
+        // Make the compiler retire these loads HERE: if they were still pending (in its scoreboard) at
+        // loop entry it would put an s_waitcnt vmcnt(0) in front of the first MFMA of every iteration
+        // and drain the in-flight row-block DMA each time.
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            asm volatile("" : "+v"(qh[kb]));
+            asm volatile("" : "+v"(ql[kb]));
+        }
+    }
+    const int qlocal = wave * 16 + (lane & 15);
+    const bool q_valid = qlocal < nq;
+    const unsigned sub_row = 4u * (unsigned)(lane >> 4);
+
+    float best_s = -FLT_MAX;
+    unsigned best_row = 0xFFFFFFFFu;
+    float tau = -INFINITY;
+    u64* wave_lists = nullptr;
+    u64* my_list = nullptr;
+    if (KMODE == 1) {
+        wave_lists = cand + ((size_t)b * kStreamQ + (size_t)wave * 16) * kStreamCap;
+        my_list = wave_lists + (size_t)(lane & 15) * kStreamCap;
+    }
+
+    for (int it = 0; it < n_my; ++it) {
+        // stage `it` has landed (ours), everyone is done reading the slot we are about to refill
+        if (it + 1 < n_my)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 2 < n_my) issue_row_block<NKB>(X, b + (it + 2) * G, lds + ((it + 2) % 3) * RB_BYTES, wave, lane);
+
+        if (wave_active) {
+            const char* p = lds + (it % 3) * RB_BYTES + lane * 16;
+            f32x4 aH = {0.f, 0.f, 0.f, 0.f}, aC1 = {0.f, 0.f, 0.f, 0.f}, aC2 = {0.f, 0.f, 0.f, 0.f};
+            // LDS -> register prefetch PF k-blocks ahead of the MFMAs that consume them
+            constexpr int PF = (KMODE == 0) ? 3 : 2;  // KMODE 1 needs the registers for list maintenance
+            half8 xh[PF], xl[PF];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                xh[i] = *(const half8*)(p + i * 2 * kFragBytes);
+                xl[i] = *(const half8*)(p + i * 2 * kFragBytes + kFragBytes);
+            }
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const half8 ch = xh[kb % PF], cl = xl[kb % PF];
+                if (kb + PF < NKB) {
+                    xh[kb % PF] = *(const half8*)(p + (kb + PF) * 2 * kFragBytes);
+                    xl[kb % PF] = *(const half8*)(p + (kb + PF) * 2 * kFragBytes + kFragBytes);
+                }
+                aH = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, qh[kb], aH, 0, 0, 0);
+                aC1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, qh[kb], aC1, 0, 0, 0);
+                aC2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, ql[kb], aC2, 0, 0, 0);
+            }
+            // pin the issue order: 2*PF reads up front, then per k-block {2 reads for kb+PF, 3 MFMAs of kb}
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (kb + PF < NKB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            }
+            // C layout: lane holds rows 4*(lane>>4)+r (corpus), column lane&15 (query)
+            const unsigned row0 = (unsigned)(b + it * G) * 16u + sub_row;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = aH[r] + (aC1[r] + aC2[r]) * kLoInv;
+                unsigned row = row0 + r;
+                bool ok = (long long)row < n_rows;
+                if (KMODE == 0) {
+                    if (ok && s > best_s) { best_s = s; best_row = row; }
+                } else {
+                    consider(s, row, ok && q_valid, tau, my_list, lds_cnt + qlocal);
+                }
+            }
+            if (KMODE == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wave_prune_if_needed<kStreamCap / 64, kStreamCap>(wave_lists, lds_cnt + wave * 16, k, lane, tau, false, nullptr);
+            }
+        }
+    }
+
+    if (KMODE == 0) {
+        u64 key = make_key(best_s, best_row);
+        // lanes l, l^16, l^32, l^48 hold the same query
+        u64 o = __shfl_xor(key, 16);
+        key = o > key ? o : key;
+        o = __shfl_xor(key, 32);
+        key = o > key ? o : key;
+        if (lane < 16 && q_valid && best) atomicMax(best + qlocal, key);
+    } else if (wave_active) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wave_prune_if_needed<kStreamCap / 64, kStreamCap>(wave_lists, lds_cnt + wave * 16, k, lane, tau, true,
+                                                          cand_kth + (size_t)b * kStreamQ + wave * 16);
+        if (lane < 16) cand_cnt[(size_t)b * kStreamQ + qlocal] = lds_cnt[qlocal];
+    }
+}
+
+// ---- generic kernel: any d (multiple of 32), fp32 FMA on the reconstructed values ------------------
+// Correctness reference on the device and fallback for shapes the stream kernel does not cover.
+__global__ void __launch_bounds__(256)
+mips_generic_kernel(const char* __restrict__ X, long long n_rows, int n_rb, int nkb, const float* __restrict__ q, int nq,
+                    u64* __restrict__ cand, int* __restrict__ cand_cnt, u64* __restrict__ cand_kth, int k) {
+    __shared__ int lds_cnt[kGenericQ];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int d = nkb * 32;
+    if (threadIdx.x < kGenericQ) lds_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int qlocal = wave * 16 + (lane & 15);
+    const bool q_valid = qlocal < nq;
+    const bool wave_active = wave * 16 < nq;
+    const float* qp = q + (size_t)(q_valid ? qlocal : 0) * d;
+    const int g4 = lane >> 4;
+    float tau = -INFINITY;
+    u64* wave_lists = cand + ((size_t)blockIdx.x * kGenericQ + (size_t)wave * 16) * kGenericCap;
+    u64* my_list = wave_lists + (size_t)(lane & 15) * kGenericCap;
+    const size_t rb_bytes = (size_t)nkb * 2 * kFragBytes;
+    if (wave_active) {
+        for (int rb = blockIdx.x; rb < n_rb; rb += gridDim.x) {
+            const char* blk = X + (size_t)rb * rb_bytes;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < nkb; ++kb) {
+                for (int gp = 0; gp < 4; ++gp) {
+                    float qv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) qv[j] = qp[kb * 32 + gp * 8 + j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const char* e = blk + (size_t)kb * 2 * kFragBytes + (size_t)((4 * g4 + r) + 16 * gp) * 16;
+                        half8 h = *(const half8*)e;
+                        half8 l = *(const half8*)(e + kFragBytes);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[r] = fmaf((float)h[j] + (float)l[j] * kLoInv, qv[j], acc[r]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                unsigned row = (unsigned)rb * 16u + 4u * g4 + r;
+                consider(acc[r], row, ((long long)row < n_rows) && q_valid, tau, my_list, lds_cnt + qlocal);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wave_prune_if_needed<kGenericCap / 64, kGenericCap>(wave_lists, lds_cnt + wave * 16, k, lane, tau, false, nullptr);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wave_prune_if_needed<kGenericCap / 64, kGenericCap>(wave_lists, lds_cnt + wave * 16, k, lane, tau, true,
+                                                            cand_kth + (size_t)blockIdx.x * kGenericQ + wave * 16);
+        if (lane < 16) cand_cnt[(size_t)blockIdx.x * kGenericQ + qlocal] = lds_cnt[qlocal];
+    }
+}
+
+// ---- result kernels ----------------------------------------------------------------------------------
+__global__ void fill_empty_kernel(float* D, long long* I, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { D[i] = -FLT_MAX; I[i] = -1; }
+}
+
+// k == 1: best[nq] -> D, I
+__global__ void finalize_top1_kernel(const u64* __restrict__ best, int nq, float* __restrict__ D, long long* __restrict__ I, long long id_offset) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    u64 key = best[q];
+    unsigned row = key_row(key);
+    if (key == 0ull || row == 0xFFFFFFFFu) { D[q] = -FLT_MAX; I[q] = -1; }
+    else { D[q] = key_score(key); I[q] = id_offset + (long long)row; }
+}
+
+__device__ inline int block_sum_256(int v, int* red) {
+    // red: LDS int[4]
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// general k: merge G per-workgroup lists of one query group. One 256-thread block per query.
+__global__ void __launch_bounds__(256)
+merge_lists_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_cnt, const u64* __restrict__ cand_kth, int G, int qcap,
+                   int cap, int k, float* __restrict__ D, long long* __restrict__ I, long long id_offset) {
+    __shared__ u64 keys[kMergeLds];
+    __shared__ u64 sel[kKMax];
+    __shared__ int red[4];
+    __shared__ u64 s_u64[4];
+    __shared__ int s_n;
+    const int ql = blockIdx.x;
+    const int tid = threadIdx.x;
+    float* Dq = D + (size_t)ql * k;
+    long long* Iq = I + (size_t)ql * k;
+
+    // lower bound on the global k-th key: the largest per-list k-th key
+    u64 t0 = 0ull;
+    int total = 0;
+    for (int w = tid; w < G; w += 256) {
+        u64 v = cand_kth[(size_t)w * qcap + ql];
+        t0 = v > t0 ? v : t0;
+        total += cand_cnt[(size_t)w * qcap + ql];
+    }
+    for (int o = 32; o > 0; o >>= 1) { u64 v = __shfl_xor(t0, o); t0 = v > t0 ? v : t0; }
+    if ((tid & 63) == 0) s_u64[tid >> 6] = t0;
+    total = block_sum_256(total, red);
+    t0 = s_u64[0];
+    for (int i = 1; i < 4; ++i) t0 = s_u64[i] > t0 ? s_u64[i] : t0;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+
+    // survivors (keys >= t0) -> LDS when they fit
+    int surv = 0;
+    for (int w = 0; w < G; ++w) {
+        int c = cand_cnt[(size_t)w * qcap + ql];
+        const u64* lst = cand + ((size_t)w * qcap + ql) * cap;
+        for (int i = tid; i < c; i += 256) {
+            u64 v = lst[i];
+            if (v >= t0) {
+                int pos = atomicAdd(&s_n, 1);
+                if (pos < kMergeLds) keys[pos] = v;
+                ++surv;
+            }
+        }
+    }
+    __syncthreads();
+    const int S = s_n;
+    const bool in_lds = S <= kMergeLds;
+    const int kk = total < k ? total : k;  // how many real results exist
+    (void)surv;
+
+    // k-th largest survivor by bisection on the 64-bit key
+    u64 t = 0ull;
+    if (kk > 0) {
+        for (int bit = 63; bit >= 0; --bit) {
+            u64 c = t | (1ull << bit);
+            int n = 0;
+            if (in_lds) {
+                for (int i = tid; i < S; i += 256) n += keys[i] >= c;
+            } else {
+                for (int w = 0; w < G; ++w) {
+                    int cc = cand_cnt[(size_t)w * qcap + ql];
+                    const u64* lst = cand + ((size_t)w * qcap + ql) * cap;
+                    for (int i = tid; i < cc; i += 256) n += lst[i] >= c;
+                }
+            }
+            n = block_sum_256(n, red);
+            if (n >= kk) t = c;
+        }
+    }
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    if (kk > 0) {
+        if (in_lds) {
+            for (int i = tid; i < S; i += 256)
+                if (keys[i] >= t) sel[atomicAdd(&s_n, 1)] = keys[i];
+        } else {
+            for (int w = 0; w < G; ++w) {
+                int cc = cand_cnt[(size_t)w * qcap + ql];
+                const u64* lst = cand + ((size_t)w * qcap + ql) * cap;
+                for (int i = tid; i < cc; i += 256)
+                    if (lst[i] >= t) sel[atomicAdd(&s_n, 1)] = lst[i];
+            }
+        }
+    }
+    __syncthreads();
+    // exactly kk selected; order by rank counting (keys are unique)
+    for (int i = tid; i < k; i += 256) {
+        if (i < kk) {
+            u64 me = sel[i];
+            int rank = 0;
+            for (int j = 0; j < kk; ++j) rank += sel[j] > me;
+            Dq[rank] = key_score(me);
+            Iq[rank] = id_offset + (long long)key_row(me);
+        } else {
+            Dq[i] = -FLT_MAX;
+            Iq[i] = -1;
+        }
+    }
+}
+
+// cross-shard merge (mdr_topk_merge): entries compare by (score desc, id asc, position asc)
+__global__ void __launch_bounds__(256)
+merge_parts_kernel(const float* __restrict__ Dp, const long long* __restrict__ Ip, int nparts, int nq, int k, float* __restrict__ D,
+                   long long* __restrict__ I) {
+    const int q = blockIdx.x;
+    const int T = nparts * k;
+    for (int i = threadIdx.x; i < k; i += 256) { D[(size_t)q * k + i] = -FLT_MAX; I[(size_t)q * k + i] = -1; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += 256) {
+        int p = i / k, e = i - p * k;
+        size_t at = ((size_t)p * nq + q) * k + e;
+        float s = Dp[at];
+        long long id = Ip[at];
+        if (id < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < T; ++j) {
+            int pj = j / k, ej = j - pj * k;
+            size_t aj = ((size_t)pj * nq + q) * k + ej;
+            long long idj = Ip[aj];
+            if (idj < 0) continue;
+            float sj = Dp[aj];
+            rank += (sj > s) || (sj == s && (idj < id || (idj == id && j < i)));
+        }
+        if (rank < k) { D[(size_t)q * k + rank] = s; I[(size_t)q * k + rank] = id; }
+    }
+}
+
+}  // namespace
+}  // namespace mdr
+
+// ======================================================================================================
+// host side
+// ======================================================================================================
+using namespace mdr;
+
+struct mdr_index {
+    int d = 0, nkb = 0, storage = 0, device = 0;
+    int num_cus = 256;
+    long long ntotal = 0;
+    long long cap_rows = 0;  // multiple of 16
+    char* data = nullptr;    // fragment-tiled shard
+    int* flags = nullptr;    // device int: bit0 = range error seen by a conversion
+    void* stage = nullptr;   // device staging for host-sourced add()
+    size_t stage_bytes = 0;
+    int variant = 0;
+    const char* last_kernel = "none";
+};
+
+namespace {
+
+size_t bytes_per_row(const mdr_index* h) { return (size_t)h->d * 4; }
+
+int grow(mdr_index* h, long long need_rows, hipStream_t st) {
+    long long need = (need_rows + 15) / 16 * 16;
+    if (need <= h->cap_rows) return MDR_OK;
+    long long ncap = need;  // first reservation is exact; later ones grow by 1.5x
+    if (h->cap_rows) {
+        long long geo = (h->cap_rows + h->cap_rows / 2 + 15) / 16 * 16;
+        if (geo > ncap) ncap = geo;
+    }
+    char* nd = nullptr;
+    MDR_HIP_TRY(hipMalloc((void**)&nd, (size_t)ncap * bytes_per_row(h)));
+    size_t used = (size_t)((h->ntotal + 15) / 16 * 16) * bytes_per_row(h);
+    if (used) MDR_HIP_TRY(hipMemcpyAsync(nd, h->data, used, hipMemcpyDeviceToDevice, st));
+    MDR_HIP_TRY(hipMemsetAsync(nd + used, 0, (size_t)ncap * bytes_per_row(h) - used, st));
+    MDR_HIP_TRY(hipStreamSynchronize(st));
+    if (h->data) MDR_HIP_TRY(hipFree(h->data));
+    h->data = nd;
+    h->cap_rows = ncap;
+    return MDR_OK;
+}
+
+template <typename T>
+int launch_convert(const T* src_dev, long long n_valid, long long n_total, int d, long long row0, char* dst, int* flags, hipStream_t st) {
+    long long threads = n_total * (d / 8);
+    if (threads == 0) return MDR_OK;
+    long long blocks = (threads + 255) / 256;
+    hipLaunchKernelGGL(convert_to_frag_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, src_dev, n_valid, n_total, d, row0, dst, flags);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
+int convert_any(const void* src_dev, int dtype, long long n_valid, long long n_total, int d, long long row0, char* dst, int* flags,
+                hipStream_t st) {
+    switch (dtype) {
+        case MDR_DT_F32: return launch_convert((const float*)src_dev, n_valid, n_total, d, row0, dst, flags, st);
+        case MDR_DT_BF16: return launch_convert((const unsigned short*)src_dev, n_valid, n_total, d, row0, dst, flags, st);
+        case MDR_DT_F16: return launch_convert((const _Float16*)src_dev, n_valid, n_total, d, row0, dst, flags, st);
+        default: return set_error(MDR_E_INVALID, "unknown src_dtype %d", dtype);
+    }
+}
+
+size_t elem_size(int dtype) { return dtype == MDR_DT_F32 ? 4 : 2; }
+
+bool stream_kernel_supports(const mdr_index* h, int k) { return h->d == 768 && k <= 128; }
+
+struct SearchPlan {
+    bool stream;
+    int qgroup;      // queries per pass
+    int cap;         // candidate slots per (wg, query)
+    int G;           // workgroups
+    size_t off_qfrag, off_best, off_cand, off_cnt, off_kth, total;
+};
+
+SearchPlan make_plan(const mdr_index* h, int nq, int k) {
+    SearchPlan p{};
+    int variant = h->variant;
+    p.stream = (variant == 2) || (variant == 0 && stream_kernel_supports(h, k));
+    if (p.stream && !stream_kernel_supports(h, k)) p.stream = false;
+    long long n_rb = (h->ntotal + 15) / 16;
+    if (p.stream) {
+        p.qgroup = kStreamQ;
+        p.cap = kStreamCap;
+        p.G = (int)(n_rb < h->num_cus ? (n_rb > 0 ? n_rb : 1) : h->num_cus);
+    } else {
+        p.qgroup = kGenericQ;
+        p.cap = kGenericCap;
+        long long g = (long long)h->num_cus * 2;
+        p.G = (int)(n_rb < g ? (n_rb > 0 ? n_rb : 1) : g);
+    }
+    int ngroups = (nq + p.qgroup - 1) / p.qgroup;
+    size_t o = 0;
+    p.off_qfrag = o;
+    o += align_up(p.stream ? (size_t)ngroups * p.qgroup * h->d * 4 : 0, 256);
+    p.off_best = o;
+    o += align_up((size_t)(nq > 0 ? nq : 1) * 8, 256);
+    bool lists = !(p.stream && k == 1);
+    p.off_cand = o;
+    o += align_up(lists ? (size_t)p.G * p.qgroup * p.cap * 8 : 0, 256);
+    p.off_cnt = o;
+    o += align_up(lists ? (size_t)p.G * p.qgroup * 4 : 0, 256);
+    p.off_kth = o;
+    o += align_up(lists ? (size_t)p.G * p.qgroup * 8 : 0, 256);
+    p.total = o + 256;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdr_index_create(int d, int storage, int device, mdr_index** out) {
+    MDR_REQUIRE(out != nullptr, "out is NULL");
+    MDR_REQUIRE(d > 0 && d % 32 == 0 && d <= 1024, "d=%d unsupported: must be a multiple of 32, <= 1024", d);
+    MDR_REQUIRE(storage == MDR_STORE_F32X2H, "storage %d not implemented (only MDR_STORE_F32X2H)", storage);
+    int ndev = 0;
+    MDR_HIP_TRY(hipGetDeviceCount(&ndev));
+    MDR_REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
+    DeviceGuard g(device);
+    if (!g.ok) return set_error(MDR_E_HIP, "hipSetDevice(%d) failed", device);
+    mdr_index* h = new (std::nothrow) mdr_index();
+    MDR_REQUIRE(h != nullptr, "out of host memory");
+    h->d = d;
+    h->nkb = d / 32;
+    h->storage = storage;
+    h->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
+    if (hipMalloc((void**)&h->flags, 256) != hipSuccess || hipMemset(h->flags, 0, 256) != hipSuccess) {
+        delete h;
+        return set_error(MDR_E_HIP, "hipMalloc(flags) failed");
+    }
+    *out = h;
+    return MDR_OK;
+}
+
+int mdr_index_free(mdr_index* h) {
+    if (!h) return MDR_OK;
+    DeviceGuard g(h->device);
+    if (h->data) (void)hipFree(h->data);
+    if (h->flags) (void)hipFree(h->flags);
+    if (h->stage) (void)hipFree(h->stage);
+    delete h;
+    return MDR_OK;
+}
+
+int mdr_index_reserve(mdr_index* h, int64_t n_rows) {
+    MDR_REQUIRE(h != nullptr, "index handle is NULL");
+    MDR_REQUIRE(n_rows >= 0 && n_rows < 0xFFFFFFF0ll, "n_rows out of range");
+    DeviceGuard g(h->device);
+    return grow(h, n_rows, nullptr);
+}
+
+int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int rows_on_device, void* stream) {
+    MDR_REQUIRE(h != nullptr, "index handle is NULL");
+    MDR_REQUIRE(n >= 0, "n < 0");
+    MDR_REQUIRE(n == 0 || rows != nullptr, "rows is NULL");
+    MDR_REQUIRE(src_dtype >= MDR_DT_F32 && src_dtype <= MDR_DT_F16, "unknown src_dtype %d", src_dtype);
+    MDR_REQUIRE(h->ntotal + n < 0xFFFFFFF0ll, "index would exceed 2^32-16 rows per shard");
+    if (n == 0) return MDR_OK;
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = grow(h, h->ntotal + n, st);
+    if (rc) return rc;
+    const size_t row_src = (size_t)h->d * elem_size(src_dtype);
+    if (rows_on_device) {
+        rc = convert_any(rows, src_dtype, n, n, h->d, h->ntotal, h->data, h->flags, st);
+        if (rc) return rc;
+    } else {
+        // chunked H2D through a device staging buffer (<= 256 MiB), converting straight into the shard
+        const long long chunk_rows = (long long)((256ull << 20) / row_src);
+        size_t need = (size_t)(n < chunk_rows ? n : chunk_rows) * row_src;
+        if (need > h->stage_bytes) {
+            if (h->stage) MDR_HIP_TRY(hipFree(h->stage));
+            h->stage = nullptr;
+            h->stage_bytes = 0;
+            MDR_HIP_TRY(hipMalloc(&h->stage, need));
+            h->stage_bytes = need;
+        }
+        for (long long r0 = 0; r0 < n; r0 += chunk_rows) {
+            long long nr = n - r0 < chunk_rows ? n - r0 : chunk_rows;
+            MDR_HIP_TRY(hipMemcpyAsync(h->stage, (const char*)rows + (size_t)r0 * row_src, (size_t)nr * row_src, hipMemcpyHostToDevice, st));
+            rc = convert_any(h->stage, src_dtype, nr, nr, h->d, h->ntotal + r0, h->data, h->flags, st);
+            if (rc) return rc;
+            MDR_HIP_TRY(hipStreamSynchronize(st));  // staging buffer is reused; host buffer must be consumed before return
+        }
+    }
+    int flag = 0;
+    MDR_HIP_TRY(hipMemcpyAsync(&flag, h->flags, sizeof(int), hipMemcpyDeviceToHost, st));
+    MDR_HIP_TRY(hipStreamSynchronize(st));
+    if (flag) {
+        MDR_HIP_TRY(hipMemsetAsync(h->flags, 0, sizeof(int), st));
+        return set_error(MDR_E_RANGE, "add(): a value is non-finite or |x| > 32768, not representable in F32X2H storage; rows were not added");
+    }
+    h->ntotal += n;
+    return MDR_OK;
+}
+
+int64_t mdr_index_ntotal(const mdr_index* h) { return h ? h->ntotal : 0; }
+int mdr_index_dim(const mdr_index* h) { return h ? h->d : 0; }
+int64_t mdr_index_stream_bytes(const mdr_index* h) { return h ? (int64_t)((h->ntotal + 15) / 16 * 16) * (int64_t)bytes_per_row(h) : 0; }
+
+int mdr_index_set_variant(mdr_index* h, int variant) {
+    MDR_REQUIRE(h != nullptr, "index handle is NULL");
+    MDR_REQUIRE(variant >= 0 && variant <= 2, "variant must be 0 (auto), 1 (generic) or 2 (stream)");
+    h->variant = variant;
+    return MDR_OK;
+}
+
+const char* mdr_index_last_kernel(const mdr_index* h) { return h ? h->last_kernel : "none"; }
+
+size_t mdr_index_search_workspace_bytes(const mdr_index* h, int nq, int k) {
+    if (!h || nq < 0 || k < 1 || k > kKMax) return 0;
+    return make_plan(h, nq, k).total;
+}
+
+int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_dev, int64_t* I_dev, int64_t id_offset, void* workspace_dev,
+                     size_t workspace_bytes, void* stream) {
+    MDR_REQUIRE(h != nullptr, "index handle is NULL");
+    MDR_REQUIRE(nq >= 0, "nq < 0");
+    MDR_REQUIRE(k >= 1 && k <= kKMax, "k=%d out of range [1, %d]", k, kKMax);
+    if (nq == 0) return MDR_OK;
+    MDR_REQUIRE(q_dev && D_dev && I_dev, "NULL query/result pointer");
+    if (h->variant == 2 && !stream_kernel_supports(h, k))
+        return set_error(MDR_E_INVALID, "stream kernel forced but unsupported for d=%d k=%d (needs d=768, k<=128)", h->d, k);
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (h->ntotal == 0) {
+        long long n = (long long)nq * k;
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, D_dev, (long long*)I_dev, n);
+        MDR_HIP_TRY(hipGetLastError());
+        h->last_kernel = "fill_empty_kernel";
+        return MDR_OK;
+    }
+    SearchPlan p = make_plan(h, nq, k);
+    if (!workspace_dev || workspace_bytes < p.total)
+        return set_error(MDR_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", p.total, workspace_bytes);
+    char* ws = (char*)(((uintptr_t)workspace_dev + 255) & ~(uintptr_t)255);
+    const int n_rb = (int)((h->ntotal + 15) / 16);
+    u64* best = (u64*)(ws + p.off_best);
+    u64* cand = (u64*)(ws + p.off_cand);
+    int* cnt = (int*)(ws + p.off_cnt);
+    u64* kth = (u64*)(ws + p.off_kth);
+    const int ngroups = (nq + p.qgroup - 1) / p.qgroup;
+
+    if (p.stream) {
+        char* qfrag = ws + p.off_qfrag;
+        int rc = launch_convert(q_dev, (long long)nq, (long long)ngroups * p.qgroup, h->d, 0, qfrag, h->flags + 1, st);
+        if (rc) return rc;
+        constexpr int NKB = 24;
+        const size_t rb_bytes = (size_t)NKB * 2 * kFragBytes;
+        const size_t lds_bytes = 3 * rb_bytes + (k == 1 ? 0 : kStreamQ * sizeof(int));
+        static bool attr_done[2] = {false, false};
+        if (k == 1) {
+            if (!attr_done[0]) {
+                MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_stream_kernel<NKB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * rb_bytes)));
+                attr_done[0] = true;
+            }
+            MDR_HIP_TRY(hipMemsetAsync(best, 0, (size_t)nq * 8, st));
+            for (int gi = 0; gi < ngroups; ++gi) {
+                int nqg = nq - gi * p.qgroup < p.qgroup ? nq - gi * p.qgroup : p.qgroup;
+                hipLaunchKernelGGL((mips_stream_kernel<NKB, 0>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->data, (long long)h->ntotal, n_rb,
+                                   (const char*)(qfrag + (size_t)gi * p.qgroup * h->d * 4), nqg, best + (size_t)gi * p.qgroup, (u64*)nullptr,
+                                   (int*)nullptr, (u64*)nullptr, 1);
+                MDR_HIP_TRY(hipGetLastError());
+            }
+            hipLaunchKernelGGL(finalize_top1_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, (const u64*)best, nq, D_dev, (long long*)I_dev,
+                               (long long)id_offset);
+            MDR_HIP_TRY(hipGetLastError());
+            h->last_kernel = "mips_stream_kernel<24,0>";
+        } else {
+            if (!attr_done[1]) {
+                MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_stream_kernel<NKB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)(3 * rb_bytes + kStreamQ * sizeof(int))));
+                attr_done[1] = true;
+            }
+            for (int gi = 0; gi < ngroups; ++gi) {
+                int nqg = nq - gi * p.qgroup < p.qgroup ? nq - gi * p.qgroup : p.qgroup;
+                MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * p.qgroup * 4, st));
+                MDR_HIP_TRY(hipMemsetAsync(kth, 0, (size_t)p.G * p.qgroup * 8, st));
+                hipLaunchKernelGGL((mips_stream_kernel<NKB, 1>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->data, (long long)h->ntotal, n_rb,
+                                   (const char*)(qfrag + (size_t)gi * p.qgroup * h->d * 4), nqg, (u64*)nullptr, cand, cnt, kth, k);
+                MDR_HIP_TRY(hipGetLastError());
+                hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.G, p.qgroup,
+                                   p.cap, k, D_dev + (size_t)gi * p.qgroup * k, (long long*)I_dev + (size_t)gi * p.qgroup * k, (long long)id_offset);
+                MDR_HIP_TRY(hipGetLastError());
+            }
+            h->last_kernel = "mips_stream_kernel<24,1>";
+        }
+    } else {
+        for (int gi = 0; gi < ngroups; ++gi) {
+            int nqg = nq - gi * p.qgroup < p.qgroup ? nq - gi * p.qgroup : p.qgroup;
+            MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * p.qgroup * 4, st));
+            MDR_HIP_TRY(hipMemsetAsync(kth, 0, (size_t)p.G * p.qgroup * 8, st));
+            hipLaunchKernelGGL(mips_generic_kernel, dim3(p.G), dim3(256), 0, st, (const char*)h->data, (long long)h->ntotal, n_rb, h->nkb,
+                               q_dev + (size_t)gi * p.qgroup * h->d, nqg, cand, cnt, kth, k);
+            MDR_HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.G, p.qgroup, p.cap,
+                               k, D_dev + (size_t)gi * p.qgroup * k, (long long*)I_dev + (size_t)gi * p.qgroup * k, (long long)id_offset);
+            MDR_HIP_TRY(hipGetLastError());
+        }
+        h->last_kernel = "mips_generic_kernel";
+    }
+    return MDR_OK;
+}
+
+int mdr_topk_merge(const float* D_parts_dev, const int64_t* I_parts_dev, int nparts, int nq, int k, float* D_dev, int64_t* I_dev, void* stream) {
+    MDR_REQUIRE(nparts >= 1 && nq >= 0 && k >= 1 && k <= kKMax, "bad merge shape nparts=%d nq=%d k=%d", nparts, nq, k);
+    if (nq == 0) return MDR_OK;
+    MDR_REQUIRE(D_parts_dev && I_parts_dev && D_dev && I_dev, "NULL pointer");
+    hipLaunchKernelGGL(merge_parts_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, D_parts_dev, (const long long*)I_parts_dev, nparts, nq, k, D_dev,
+                       (long long*)I_dev);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+"""Flat inner-product index on one MI355X -- the host-side mirror of `faiss.IndexFlatIP` as the
+reference uses it (/root/reference/scripts/eval/eval_mhop_retrieval.py:121-125,155,179):
+
+    index = IndexFlatIP(d); index.add(xb); D, I = index.search(x, k)
+
+Same names, argument meaning and result layout (D float32 [n,k] descending, I int64 [n,k], -1 /
+-FLT_MAX padding when fewer than k rows). numpy in -> numpy out (drop-in for the reference loop);
+torch CUDA tensor in -> torch CUDA tensors out with no host round trip and no device sync.
+
+All arithmetic happens in libmdrhip.so (csrc/mdr_mips.hip); this file only moves pointers.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_TORCH_DT = {torch.float32: _lib.MDR_DT_F32, torch.bfloat16: _lib.MDR_DT_BF16, torch.float16: _lib.MDR_DT_F16}
+_NP_DT = {np.dtype(np.float32): _lib.MDR_DT_F32, np.dtype(np.float16): _lib.MDR_DT_F16}
+
+
+class IndexFlatIP:
+    """Brute-force maximum-inner-product index resident in HBM."""
+
+    def __init__(self, d, device=None, storage=_lib.MDR_STORE_F32X2H):
+        if not torch.cuda.is_available():
+            raise RuntimeError("IndexFlatIP needs a HIP device (there is no CPU fallback)")
+        self.d = int(d)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().mdr_index_create(self.d, storage, self.device.index, ctypes.byref(self._h)))
+        self._ws = None
+        self.id_offset = 0  # global id of local row 0 (set by ShardedIndexFlatIP)
+
+    # -- faiss-compatible surface ---------------------------------------------------------------------
+    @property
+    def ntotal(self):
+        return int(_lib.lib().mdr_index_ntotal(self._h))
+
+    def reserve(self, n_rows):
+        _lib.check(_lib.lib().mdr_index_reserve(self._h, int(n_rows)))
+
+    def add(self, x):
+        """Append rows. x: [n, d] numpy (float32/float16) or torch tensor (cpu or cuda; f32/f16/bf16)."""
+        L = _lib.lib()
+        if isinstance(x, np.ndarray):
+            if x.dtype not in _NP_DT:
+                x = x.astype(np.float32)  # eval_mhop_retrieval.py:94 `.astype('float32')`
+            x = np.ascontiguousarray(x)
+            self._check_shape(x.shape)
+            # big host arrays (np.load(mmap_mode='r') works too) go through the library's chunked upload
+            _lib.check(L.mdr_index_add(self._h, ctypes.c_void_p(x.ctypes.data), x.shape[0], _NP_DT[x.dtype], 0,
+                                       _lib.current_stream_ptr(self.device)))
+            return
+        if not torch.is_tensor(x):
+            raise TypeError("add() expects a numpy array or a torch tensor")
+        if x.dtype not in _TORCH_DT:
+            x = x.float()
+        x = x.contiguous()
+        self._check_shape(tuple(x.shape))
+        if x.is_cuda and x.device != self.device:
+            x = x.to(self.device)
+        _lib.check(L.mdr_index_add(self._h, ctypes.c_void_p(x.data_ptr()), x.shape[0], _TORCH_DT[x.dtype], int(x.is_cuda),
+                                   _lib.current_stream_ptr(self.device)))
+
+    def search(self, x, k):
+        """D, I = top-k rows by inner product, best first. numpy in -> numpy out; cuda tensor in -> cuda out."""
+        as_numpy = isinstance(x, np.ndarray)
+        if as_numpy:
+            q = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.device)
+        else:
+            q = x.to(device=self.device, dtype=torch.float32).contiguous()
+        D, I = self.search_device(q, k)
+        if as_numpy:
+            return D.cpu().numpy(), I.cpu().numpy()
+        return D, I
+
+    def search_device(self, q, k, out=None):
+        """q: float32 cuda [nq, d] contiguous. Enqueues on torch's current stream; no sync."""
+        if q.dim() != 2 or q.shape[1] != self.d:
+            raise ValueError(f"query shape {tuple(q.shape)} does not match index dimension {self.d}")
+        if q.dtype != torch.float32 or not q.is_cuda or not q.is_contiguous():
+            raise ValueError("search_device() wants a contiguous float32 CUDA tensor")
+        nq, k = int(q.shape[0]), int(k)
+        L = _lib.lib()
+        need = int(L.mdr_index_search_workspace_bytes(self._h, nq, k))
+        if need == 0 and nq > 0:
+            raise ValueError(f"k={k} out of range")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        if out is None:
+            D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        else:
+            D, I = out
+        _lib.check(L.mdr_index_search(self._h, ctypes.c_void_p(q.data_ptr()), nq, k, ctypes.c_void_p(D.data_ptr()),
+                                      ctypes.c_void_p(I.data_ptr()), int(self.id_offset), ctypes.c_void_p(self._ws.data_ptr()),
+                                      self._ws.numel(), _lib.current_stream_ptr(self.device)))
+        return D, I
+
+    # -- extras ------------------------------------------------------------------------------------------
+    def stream_bytes(self):
+        """HBM bytes one search call reads for the corpus (algorithmic bytes of the roofline)."""
+        return int(_lib.lib().mdr_index_stream_bytes(self._h))
+
+    def set_variant(self, v):
+        """Test hook: 0 auto, 1 generic fp32 kernel, 2 MFMA stream kernel."""
+        _lib.check(_lib.lib().mdr_index_set_variant(self._h, int(v)))
+
+    def last_kernel(self):
+        return _lib.lib().mdr_index_last_kernel(self._h).decode()
+
+    def _check_shape(self, shape):
+        if len(shape) != 2 or shape[1] != self.d:
+            raise ValueError(f"expected [n, {self.d}] rows, got {shape}")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                _lib.lib().mdr_index_free(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+
+def topk_merge(D_parts, I_parts):
+    """[P, nq, k] cuda float32 / int64 -> merged (D [nq,k], I [nq,k]); score desc, id asc."""
+    P, nq, k = D_parts.shape
+    D_parts = D_parts.contiguous()
+    I_parts = I_parts.contiguous()
+    D = torch.empty((nq, k), dtype=torch.float32, device=D_parts.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=D_parts.device)
+    _lib.check(_lib.lib().mdr_topk_merge(ctypes.c_void_p(D_parts.data_ptr()), ctypes.c_void_p(I_parts.data_ptr()), P, nq, k,
+                                         ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
+                                         _lib.current_stream_ptr(D_parts.device)))
+    return D, I
+
+
+def shard_bounds(n_total, world_size, rank):
+    """Contiguous row blocks: rank r owns [r*ceil(N/W), min(N, (r+1)*ceil(N/W)))  (SURVEY.md §8e)."""
+    per = -(-int(n_total) // int(world_size))
+    lo = min(n_total, rank * per)
+    hi = min(n_total, lo + per)
+    return lo, hi
+
+
+class ShardedIndexFlatIP:
+    """Row-sharded flat index over the ranks of a torch.distributed process group (one process per GPU).
+
+    Each rank searches its own shard, the per-shard (D, I) lists are exchanged with ONE all_gather per
+    search (RCCL over xGMI; KB-sized, latency-bound) and every rank runs the same deterministic merge,
+    so all ranks hold identical hop-1 results and can build hop-2 queries without more communication.
+
+    `local_index` / `merge_fn` are injectable so the world_size-2 gloo tests on CPU can exercise the
+    partitioning, the collective and the id arithmetic with the oracle standing in for the kernels.
+    """
+
+    def __init__(self, d, n_total, group=None, local_index=None, merge_fn=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.d = d
+        self.n_total = int(n_total)
+        self.lo, self.hi = shard_bounds(self.n_total, self.world, self.rank)
+        self.local = local_index if local_index is not None else IndexFlatIP(d)
+        self.local.id_offset = self.lo
+        self.merge_fn = merge_fn if merge_fn is not None else topk_merge
+
+    @property
+    def ntotal(self):
+        return self.n_total
+
+    def add_local(self, x_local):
+        """Rows [lo, hi) of the global matrix, in order."""
+        self.local.add(x_local)
+
+    def add_from_global(self, xb):
+        """Convenience: slice this rank's rows out of a full (e.g. mmap'ed) matrix."""
+        self.local.add(xb[self.lo:self.hi])
+
+    def search(self, q, k):
+        D, I = self.local.search(q, k)
+        return self.search_gathered(D, I)
+
+    def search_gathered(self, D, I):
+        """Exchange this rank's (D, I) [nq, k] with every other rank and merge; identical on all ranks."""
+        if self.world == 1:
+            return D, I
+        as_numpy = isinstance(D, np.ndarray)
+        Dt = torch.from_numpy(D) if as_numpy else D
+        It = torch.from_numpy(I) if as_numpy else I
+        nq, k = Dt.shape
+        # one packed buffer -> ONE collective per hop: scores as int32 bit patterns next to the ids
+        packed = torch.stack([Dt.contiguous().view(torch.int32).to(torch.int64), It.contiguous()], 0)
+        gathered = torch.empty((self.world,) + tuple(packed.shape), dtype=torch.int64, device=packed.device)
+        self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        Dp = gathered[:, 0].to(torch.int32).view(torch.float32).reshape(self.world, nq, k)
+        Ip = gathered[:, 1].reshape(self.world, nq, k)
+        Dm, Im = self.merge_fn(Dp.contiguous(), Ip.contiguous())
+        if as_numpy:
+            return Dm.cpu().numpy(), Im.cpu().numpy()
+        return Dm, Im

@@ -1,0 +1,267 @@
+"""Two-hop beam-search retrieval: the host-side logic of
+/root/reference/scripts/eval/eval_mhop_retrieval.py:139-284 as importable functions (the reference
+keeps it inline under `__main__`), plus the device-resident variant used by bench.py.
+
+Everything numeric (encoder forward, MIPS) is delegated to libmdrhip.so through `retriever.py` and
+`index.py`; this module only wires the hops together, ranks paths and computes the metrics.
+"""
+import collections
+import json
+
+import numpy as np
+import torch
+
+
+# ------------------------------------------------------------------------------------------------------
+# host logic shared with the CLI (parity-tested against oracle/mhop_oracle.py and tests/golden/mhop.json)
+# ------------------------------------------------------------------------------------------------------
+def strip_question(q):
+    """Drop exactly one trailing '?' before encoding (eval_mhop_retrieval.py:139)."""
+    return q[:-1] if q.endswith("?") else q
+
+
+def load_corpus_dict(path_or_obj):
+    """id2doc with string keys -> {"title","text",...}; list-valued entries [title, text, (intro)] are
+    normalised (eval_mhop_retrieval.py:131-133)."""
+    id2doc = path_or_obj
+    if isinstance(path_or_obj, str):
+        with open(path_or_obj) as f:
+            id2doc = json.load(f)
+    if len(id2doc) and isinstance(next(iter(id2doc.values())), list):
+        id2doc = {k: {"title": v[0], "text": v[1]} for k, v in id2doc.items()}
+    return id2doc
+
+
+def build_hop2_pairs(batch_q, D, I, id2doc, roberta=True):
+    """(question, passage) pairs for the hop-2 encoder, row-major over (question, beam slot). A passage
+    with empty text is replaced by its title and its hop-1 score set to -inf, in place
+    (eval_mhop_retrieval.py:158-166)."""
+    pairs = []
+    ninf = float("-inf")
+    for b, q in enumerate(batch_q):
+        row = I[b]
+        for j in range(len(row)):
+            doc = id2doc[str(int(row[j]))]
+            text = doc["text"]
+            if roberta and not text.strip():
+                text = doc["title"]
+                D[b][j] = ninf
+            pairs.append((q, text))
+    return pairs
+
+
+def rank_paths(D, I, D2, I2, beam, topk):
+    """Best `topk` (hop-1 id, hop-2 id, score) chains per question (eval_mhop_retrieval.py:181-206).
+    Path score = hop-1 score + hop-2 score. Raises IndexError when topk > beam*beam, like the
+    reference. Among equal path scores the reference's order is unspecified (reversed unstable
+    argsort); here it is the same numpy expression so results coincide on every input."""
+    B = D.shape[0]
+    if topk > beam * beam:
+        raise IndexError(f"topk={topk} exceeds beam*beam={beam * beam}")
+    scores = (np.asarray(D)[:, :, None] + np.asarray(D2).reshape(B, beam, beam)).reshape(B, beam * beam)
+    I2 = np.asarray(I2).reshape(B, beam, beam)
+    order = np.argsort(scores, axis=1)[:, ::-1][:, :topk]
+    out = []
+    for b in range(B):
+        i, j = np.divmod(order[b], beam)
+        out.append([(int(I[b, ii]), int(I2[b, ii, jj]), float(scores[b, o])) for ii, jj, o in zip(i, j, order[b])])
+    return out
+
+
+def question_metrics(chains, sp, id2doc):
+    """p_recall / p_em / recall_1 / path_covered on titles (eval_mhop_retrieval.py:219-242)."""
+    if len(set(sp)) != 2:
+        raise AssertionError("expected exactly two distinct supporting titles")
+    path_titles = [(id2doc[str(h1)]["title"], id2doc[str(h2)]["title"]) for h1, h2, _ in chains]
+    retrieved = {t for p in path_titles for t in p}
+    hop1 = {p[0] for p in path_titles}
+    hit = [t in retrieved for t in sp]
+    gold = set(sp)
+    return {"p_recall": int(any(hit)), "p_em": int(all(hit)), "recall_1": int(any(t in hop1 for t in sp)),
+            "path_covered": int(any(set(p) == gold for p in path_titles))}
+
+
+def output_record(item, chains, id2doc):
+    """One JSONL record (eval_mhop_retrieval.py:246-258): keys in this order, original question text."""
+    return {"_id": item["_id"], "question": item["question"],
+            "candidate_chains": [[id2doc[str(h1)], id2doc[str(h2)]] for h1, h2, _ in chains]}
+
+
+def summary_lines(metrics):
+    """The log lines of eval_mhop_retrieval.py:265-284 (retrieval branch), verbatim format."""
+    groups = collections.OrderedDict()
+    for m in metrics:
+        groups.setdefault(m["type"], []).append(m)
+
+    def block(ms):
+        return [f"\tAvg PR: {np.mean([m['p_recall'] for m in ms])}", f"\tAvg P-EM: {np.mean([m['p_em'] for m in ms])}",
+                f"\tAvg 1-Recall: {np.mean([m['recall_1'] for m in ms])}", f"\tPath Recall: {np.mean([m['path_covered'] for m in ms])}"]
+
+    lines = [f"Evaluating {len(metrics)} samples..."] + block(metrics)
+    for t, ms in groups.items():
+        lines.append(f"{t} Questions num: {len(ms)}")
+        lines += block(ms)
+    return lines
+
+
+def rank_paths_device(D, I, D2, I2, beam, topk):
+    """Device version of rank_paths for the resident pipeline: tensors in, tensors out, no sync.
+    D [B,beam], I [B,beam], D2/I2 [B*beam, beam] -> (hop1 [B,topk], hop2 [B,topk], score [B,topk])."""
+    B = D.shape[0]
+    scores = (D[:, :, None] + D2.view(B, beam, beam)).view(B, beam * beam)
+    s, o = torch.topk(scores, topk, dim=1)
+    i = torch.div(o, beam, rounding_mode="floor")
+    h1 = torch.gather(I, 1, i)
+    h2 = torch.gather(I2.view(B, beam * beam), 1, o)
+    return h1, h2, s
+
+
+# ------------------------------------------------------------------------------------------------------
+# bench pipeline: everything resident in HBM, synthetic inputs (no tokenizer / corpus text offline)
+# ------------------------------------------------------------------------------------------------------
+class SyntheticTwoHop:
+    """One `step()` = one batch of questions through hop-1 encode -> search -> hop-2 input assembly ->
+    hop-2 encode -> search -> path ranking, without leaving the device. Token ids follow SURVEY.md
+    §8(d): uniform in [3, vocab), <s>=0 first, </s>=2 last, pad 1, question lengths U[8,40], passage
+    lengths U[60,300]; the hop-2 passage tokens are a deterministic function of the hop-1 doc id."""
+
+    VOCAB = 50265
+
+    def __init__(self, index, batch, beam, topk, dim, device, max_q_len=70, max_q_sp_len=350, use_encoder=True,
+                 planted_rows=None, rank=0, world=1):
+        self.index, self.B, self.beam, self.topk, self.d, self.device = index, batch, beam, topk, dim, device
+        self.Lq, self.Lsp = max_q_len, max_q_sp_len
+        self.use_encoder = use_encoder
+        self.rank, self.world = rank, world
+        self.local = getattr(index, "local", index)
+        g = torch.Generator(device=device).manual_seed(2)
+        B = batch
+        self.q_len = torch.randint(8, 41, (B,), generator=g, device=device)
+        self.q_ids = torch.randint(3, self.VOCAB, (B, self.Lq), generator=g, device=device)
+        pos = torch.arange(self.Lq, device=device)[None, :]
+        self.q_mask = (pos < self.q_len[:, None]).long()
+        self.q_ids = torch.where(pos == 0, torch.zeros_like(self.q_ids), self.q_ids)
+        self.q_ids = torch.where(pos == self.q_len[:, None] - 1, torch.full_like(self.q_ids, 2), self.q_ids)
+        self.q_ids = torch.where(self.q_mask.bool(), self.q_ids, torch.ones_like(self.q_ids))
+        self.noise = 0.05 * torch.randn((B, dim), generator=g, device=device)
+        self.table = torch.randn((1024, dim), generator=g, device=device)
+        self.planted_rows = planted_rows
+        self.encoder = None
+        if use_encoder:
+            from .retriever import RobertaRetriever
+            self.encoder = RobertaRetriever.random_init(device=device, seed=3)
+        self._ev = []
+        self._search_ev = []
+
+    # -- synthetic stand-ins for the text side ---------------------------------------------------------
+    def _hop2_inputs(self, I):
+        """<s> q </s></s> doc </s> with longest-first truncation to max_q_sp_len, assembled on device."""
+        B, beam, L = self.B, self.beam, self.Lsp
+        doc = I.reshape(-1)  # [B*beam]
+        qlen = self.q_len.repeat_interleave(beam)  # includes <s> and </s>
+        dlen = 60 + (doc * 2654435761 % 241)  # U[60,300] by doc id
+        total = qlen + 1 + dlen + 1
+        over = (total - L).clamp(min=0)
+        dlen = dlen - over  # the passage is always the longer segment here -> longest-first trims it
+        pos = torch.arange(L, device=self.device)[None, :]
+        q_rep = self.q_ids.repeat_interleave(beam, 0)
+        q_pad = torch.nn.functional.pad(q_rep, (0, L - self.Lq), value=1)
+        dstart = (qlen + 1)[:, None]
+        dtok = 3 + ((doc[:, None] * 1000003 + (pos - dstart) * 7919) % (self.VOCAB - 3))
+        ids = torch.where(pos < qlen[:, None], q_pad, torch.ones_like(q_pad))
+        ids = torch.where(pos == qlen[:, None], torch.full_like(ids, 2), ids)
+        in_doc = (pos >= dstart) & (pos < dstart + dlen[:, None])
+        ids = torch.where(in_doc, dtok, ids)
+        ids = torch.where(pos == dstart + dlen[:, None], torch.full_like(ids, 2), ids)
+        mask = (pos <= dstart + dlen[:, None]).long()
+        return ids, mask
+
+    def _encode(self, ids, mask):
+        if self.world > 1:
+            # data-parallel encoder: each rank encodes a contiguous slice, embeddings are all-gathered
+            import torch.distributed as dist
+            n = ids.shape[0]
+            per = -(-n // self.world)
+            lo, hi = min(n, self.rank * per), min(n, (self.rank + 1) * per)
+            part = torch.zeros((per, self.d), device=self.device)
+            if hi > lo:
+                part[: hi - lo] = self.encoder.encode_q(ids[lo:hi], mask[lo:hi], None)
+            full = torch.empty((self.world * per, self.d), device=self.device)
+            dist.all_gather_into_tensor(full, part)
+            return full[:n].contiguous()
+        return self.encoder.encode_q(ids, mask, None)
+
+    # -- one step ----------------------------------------------------------------------------------------
+    def _mark(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _search(self, q, k):
+        e0 = self._mark()
+        D, I = self.local.search_device(q, k)
+        e1 = self._mark()
+        self._search_ev.append((e0, e1))  # the local MIPS launch only (roofline), not the exchange
+        if self.world == 1:
+            return D, I
+        return self.index.search_gathered(D, I)
+
+    def step(self):
+        ev = [self._mark()]
+        if self.use_encoder:
+            q = self._encode(self.q_ids, self.q_mask)
+        else:
+            q = self.planted_rows + self.noise
+        ev.append(self._mark())
+        D, I = self._search(q, self.beam)
+        ev.append(self._mark())
+        if self.use_encoder:
+            ids, mask = self._hop2_inputs(I)
+            ev.append(self._mark())
+            q2 = self._encode(ids, mask)
+        else:
+            ev.append(self._mark())
+            q2 = (0.5 * q).repeat_interleave(self.beam, 0) + self.table[(I.reshape(-1) % 1024)]
+        ev.append(self._mark())
+        D2, I2 = self._search(q2.contiguous(), self.beam)
+        ev.append(self._mark())
+        h1, h2, s = rank_paths_device(D, I, D2, I2, self.beam, self.topk)
+        ev.append(self._mark())
+        self._ev.append(ev)
+        return {"q": q, "D": D, "I": I, "D2": D2, "I2": I2, "hop1": h1, "hop2": h2, "score": s}
+
+    # -- reporting -----------------------------------------------------------------------------------------
+    def reset_kernel_timers(self):
+        self._ev, self._search_ev = [], []
+
+    def search_kernel_ms(self):
+        if not self._search_ev:
+            return 0.0
+        return float(np.mean([a.elapsed_time(b) for a, b in self._search_ev]))
+
+    def search_calls_timed(self):
+        return len(self._search_ev)
+
+    def stage_ms(self):
+        names = ["hop1_encode", "hop1_search", "hop2_assemble", "hop2_encode", "hop2_search", "rank_paths"]
+        if not self._ev:
+            return {}
+        acc = np.zeros(len(names))
+        for ev in self._ev:
+            acc += np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(len(names))])
+        return {n: round(float(v / len(self._ev)), 4) for n, v in zip(names, acc)}
+
+    def encoder_desc(self):
+        return "hip (RoBERTa-base geometry, random init, fp16 MFMA)" if self.use_encoder else "absent: synthetic query embeddings"
+
+    def self_check(self, out, planted):
+        """Full-size known answers: with synthetic embeddings the hop-1 best row must be the planted row;
+        always: scores are descending and a path score is the sum of its hop scores."""
+        ok = {}
+        if not self.use_encoder:
+            ok["hop1_top1_is_planted_row"] = bool(torch.equal(out["I"][:, 0], planted))
+        ok["hop1_sorted"] = bool((out["D"][:, :-1] >= out["D"][:, 1:]).all()) if self.beam > 1 else True
+        best = out["D"][:, 0] + out["D2"].view(self.B, self.beam, self.beam)[:, 0, 0]
+        ok["best_path_ge_greedy_path"] = bool((out["score"][:, 0] >= best - 1e-4).all())
+        ok["ids_in_range"] = bool(((out["hop1"] >= 0) & (out["hop2"] >= 0) & (out["hop1"] < self.index.ntotal)).all())
+        return ok
