@@ -24,11 +24,11 @@ timeout 900 python bench.py --rows 5000000 --steps 20 --warmup 3 --no-encoder $E
 
 echo "== rocprofv3 kernel stats (5M, MIPS only)"
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o mips5m -- python $REPO/bench.py --rows 5000000 --steps 10 --warmup 2 --no-encoder --no-cpu-baseline $EXTRA > $OUT/prof_stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o mips5m -- python $REPO/bench.py --rows 5000000 --steps 10 --warmup 2 --no-encoder --no-cpu-baseline $EXTRA > $OUT/prof_stats.log 2>&1
 find $OUT/prof_stats -name "*kernel_stats*" | head -3
 S=$(find $OUT/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && head -12 "$S"
 echo "== rocprofv3 pmc FETCH_SIZE (1M, MIPS only)"
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_pmc -o mips1m -- python $REPO/bench.py --rows 1000000 --steps 3 --warmup 1 --no-encoder --no-cpu-baseline $EXTRA > $OUT/prof_pmc.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_pmc -o mips1m -- python $REPO/bench.py --rows 1000000 --steps 3 --warmup 1 --no-encoder --no-cpu-baseline $EXTRA > $OUT/prof_pmc.log 2>&1
 P=$(find $OUT/prof_pmc -name "*counter_collection.csv" | head -1); [ -n "$P" ] && (head -1 "$P"; grep mips_stream "$P" | head -6)
 # keep the transfer small: drop the big traces, keep csv summaries
 find $OUT -name "*.db" -size +20M -delete 2>/dev/null
