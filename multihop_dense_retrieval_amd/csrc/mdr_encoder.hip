@@ -1,15 +1,684 @@
-// csrc/mdr_encoder.hip -- RoBERTa encoder forward (placeholder until the kernels land this round).
+// csrc/mdr_encoder.hip -- RoBERTa encoder forward + CLS projection for gfx950 (MI355X).
+//
+// Replaces   project(encoder(input_ids, mask)[0][:, 0, :])
+//   /root/reference/mdr/retrieval/models/mhop_retriever.py:23-26,40-41   (RobertaRetriever.encode_q)
+//   /root/reference/mdr/retrieval/models/retriever.py:186-190            (RobertaCtxEncoder.forward)
+// where `encoder` is HuggingFace RobertaModel (transformers 2.11, third party). Numerics follow the
+// apex-O1 regime the reference runs under (eval_mhop_retrieval.py:88-89): fp16 GEMM operands with fp32
+// accumulation; LayerNorm, softmax and GELU in fp32. See DESIGN.md §4.
+//
+// Execution is UNPADDED: tokens whose mask is 0 are dropped up front (the CLS embedding does not
+// depend on them) and every kernel works on the packed [T, hidden] token
+// matrix; T is only known on the device, so grids are sized for batch*seq_len and surplus tiles exit.
+//
+// Kernels
+//   enc_lens / enc_scan / enc_scatter   packing: lengths, cu_seqlens, token -> (row, position id)
+//   embed_ln                            word + position + type embedding gather, LayerNorm -> fp16
+//   gemm_f16<EPI>                       C = A[M,K] x W[N,K]^T on v_mfma_f32_16x16x32_f16, 128x128x64 tiles,
+//                                       global_load_lds staging (XOR-swizzled via the source address),
+//                                       fused bias / bias+GELU / bias+residual epilogues
+//   attention<NT>                       per (sequence, head, 64 queries): K and V^T of the sequence in LDS,
+//                                       S = QK^T on MFMA, fp32 softmax in registers, O = PV on MFMA
+//   layernorm                           fp32 [T,H] -> fp16 (hidden state) or fp32 (final embedding)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
 #include "mdr_common.h"
 
-struct mdr_encoder { int unused; };
+namespace mdr {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MDR_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define MDR_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- packing ---------------------------------------------------------------------------------------
+// one wave per row: number of tokens with mask != 0
+__global__ void __launch_bounds__(256) enc_lens_kernel(const long long* __restrict__ mask, int B, int L, int* __restrict__ lens) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    int n = 0;
+    for (int p0 = 0; p0 < L; p0 += 64) {
+        int p = p0 + lane;
+        bool m = p < L && mask[(size_t)b * L + p] != 0;
+        n += __popcll(__ballot(m));
+    }
+    if (lane == 0) lens[b] = n;
+}
+
+// single block: exclusive scan of lens -> cu[0..B], total
+__global__ void __launch_bounds__(1024) enc_scan_kernel(const int* __restrict__ lens, int B, int* __restrict__ cu, int* __restrict__ total) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        int i = base + tid;
+        int v = i < B ? lens[i] : 0;
+        int x = v;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int off = carry_s;
+        for (int j = 0; j < w; ++j) off += wsum[j];
+        if (i < B) cu[i] = off + x - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = off + x;
+        __syncthreads();
+    }
+    if (tid == 0) { cu[B] = carry_s; *total = carry_s; }
+}
+
+// one wave per row: packed token t = cu[b] + j  ->  source element b*L+p and RoBERTa position id
+// (position ids count input_ids != pad_id over the WHOLE row, HF create_position_ids_from_input_ids)
+__global__ void __launch_bounds__(256) enc_scatter_kernel(const long long* __restrict__ ids, const long long* __restrict__ mask, int B, int L,
+                                                          int pad_id, const int* __restrict__ cu, int* __restrict__ tok_src,
+                                                          int* __restrict__ tok_pid) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int j0 = cu[b], c0 = 0;
+    for (int p0 = 0; p0 < L; p0 += 64) {
+        int p = p0 + lane;
+        bool in = p < L;
+        bool m = in && mask[(size_t)b * L + p] != 0;
+        bool np = in && ids[(size_t)b * L + p] != (long long)pad_id;
+        unsigned long long bm = __ballot(m), bn = __ballot(np);
+        if (m) {
+            int t = j0 + __popcll(bm & lt);
+            tok_src[t] = b * L + p;
+            tok_pid[t] = np ? (c0 + __popcll(bn & lt) + 1 + pad_id) : pad_id;
+        }
+        j0 += __popcll(bm);
+        c0 += __popcll(bn);
+    }
+}
+
+// ---- embeddings + LayerNorm: one wave per packed token ------------------------------------------------
+constexpr int kMaxPerLane = 16;  // hidden <= 1024
+
+__global__ void __launch_bounds__(256)
+embed_ln_kernel(const long long* __restrict__ ids, const int* __restrict__ tok_src, const int* __restrict__ tok_pid, const int* __restrict__ total,
+                const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type0, const float* __restrict__ g,
+                const float* __restrict__ bta, int H, int vocab, int max_pos, float eps, _Float16* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= *total) return;
+    long long id = ids[tok_src[t]];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int pid = tok_pid[t];
+    pid = pid >= max_pos ? max_pos - 1 : pid;
+    const float* wr = word + (size_t)id * H;
+    const float* pr = pos + (size_t)pid * H;
+    const int n = H >> 6;
+    float x[kMaxPerLane];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i)
+        if (i < n) { int e = lane + 64 * i; x[i] = wr[e] + pr[e] + type0[e]; s += x[i]; }
+    const float mu = wave_sum(s) / H;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i)
+        if (i < n) { float dlt = x[i] - mu; v += dlt * dlt; }
+    const float rstd = rsqrtf(wave_sum(v) / H + eps);
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i)
+        if (i < n) { int e = lane + 64 * i; out[(size_t)t * H + e] = (_Float16)((x[i] - mu) * rstd * g[e] + bta[e]); }
+}
+
+// fp32 rows -> LayerNorm -> fp16 (out16) and/or fp32 (out32); one wave per row
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const float* __restrict__ in, int rows_cap, const int* __restrict__ rows_dev, int H, const float* __restrict__ g,
+                 const float* __restrict__ bta, float eps, _Float16* __restrict__ out16, float* __restrict__ out32) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rows = rows_dev ? min(*rows_dev, rows_cap) : rows_cap;
+    if (t >= rows) return;
+    const float* r = in + (size_t)t * H;
+    const int n = H >> 6;
+    float x[kMaxPerLane];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i)
+        if (i < n) { x[i] = r[lane + 64 * i]; s += x[i]; }
+    const float mu = wave_sum(s) / H;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i)
+        if (i < n) { float dlt = x[i] - mu; v += dlt * dlt; }
+    const float rstd = rsqrtf(wave_sum(v) / H + eps);
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i)
+        if (i < n) {
+            int e = lane + 64 * i;
+            float y = (x[i] - mu) * rstd * g[e] + bta[e];
+            if (out16) out16[(size_t)t * H + e] = (_Float16)y;
+            if (out32) out32[(size_t)t * H + e] = y;
+        }
+}
+
+// first token of every sequence -> dense [B, H] fp16
+__global__ void gather_cls_kernel(const _Float16* __restrict__ h, const int* __restrict__ cu, int B, int H, _Float16* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    int b = i / H, e = i - b * H;
+    out[i] = h[(size_t)cu[b] * H + e];
+}
+
+__global__ void f32_to_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (_Float16)in[i];
+}
+
+// ---- GEMM: C[M,N] = A[M,K] (fp16, row-major) x W[N,K]^T (fp16, row-major) -----------------------------
+enum { EPI_BIAS_F16 = 0, EPI_BIAS_GELU_F16 = 1, EPI_BIAS_RES_F32 = 2, EPI_BIAS_F32 = 3 };
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kGemmStage = (BM + BN) * BK * 2;  // 32 KiB per stage
+constexpr int kGemmLds = 2 * kGemmStage;
+
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+template <int EPI>
+__global__ void __launch_bounds__(256)
+gemm_f16_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M_cap,
+                const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo, const _Float16* __restrict__ res, int ldr) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int M = M_dev ? min(*M_dev, M_cap) : M_cap;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, lr = lane & 15;
+
+    // DMA plan: tile = 128 rows x 8 slots of 16 B; LDS slot p = i*256 + tid holds global chunk
+    // (row = p>>3, k-slot = (p&7) ^ (row&7)): linear LDS image, XOR swizzle applied on the source side
+    const _Float16* a_src[4];
+    const _Float16* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int p = i * 256 + tid;
+        int row = p >> 3, s = (p & 7) ^ (row & 7);
+        int ar = m0 + row;
+        ar = ar < M ? ar : M - 1;  // rows past M are computed on a valid row and never stored
+        a_src[i] = A + (size_t)ar * lda + s * 8;
+        w_src[i] = W + (size_t)(n0 + row) * K + s * 8;
+    }
+    auto issue = [&](int stage, int k0) {
+        char* base = lds + stage * kGemmStage;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(MDR_GPTR(a_src[i] + k0), MDR_LPTR(base + (i * 256 + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(MDR_GPTR(w_src[i] + k0), MDR_LPTR(base + BM * BK * 2 + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int sw0 = ((0 * 4 + g) ^ (lane & 7)) << 4, sw1 = ((1 * 4 + g) ^ (lane & 7)) << 4;
+    const int a_off = (wm * 64 + lr) * 128, w_off = BM * BK * 2 + (wn * 64 + lr) * 128;
+
+    const int KT = K / BK;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) issue(cur ^ 1, (kt + 1) * BK);
+        const char* base = lds + cur * kGemmStage;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int sw = s ? sw1 : sw0;
+            half8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const half8*)(base + a_off + t * 16 * 128 + sw);
+                wf[t] = *(const half8*)(base + w_off + t * 16 * 128 + sw);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // epilogue: lane holds C[m = .. + lr][n = .. + 4g + r], r = 0..3 (first MFMA operand = W rows)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + lr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wn * 64 + nt * 16 + 4 * g;
+            const f32x4 b4 = *(const f32x4*)(bias + n);
+            f32x4 v = acc[mt][nt] + b4;
+            if (EPI == EPI_BIAS_GELU_F16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (EPI == EPI_BIAS_RES_F32) {
+                const half4 r4 = *(const half4*)(res + (size_t)m * ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)r4[r];
+            }
+            if (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
+                half4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
+                *(half4*)((_Float16*)out + (size_t)m * ldo + n) = o;
+            } else {
+                *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
+            }
+        }
+    }
+}
+
+// ---- attention: softmax(Q K^T / 8 + mask) V for one (sequence, head, 64-query tile) --------------------
+template <int NT>  // key tiles of 16 the sequence may have (len <= 16*NT)
+__global__ void __launch_bounds__(256) attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
+                                                        _Float16* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int LP = NT * 16;
+    constexpr int VS = LP + 8;  // V^T row stride (halfs); +8 keeps 16-B alignment and staggers banks
+    _Float16* Ks = (_Float16*)lds;               // [LP][64], 128-B rows, 16-B slots XOR-swizzled by row&7
+    _Float16* Vt = (_Float16*)(lds + LP * 128);  // [64][VS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int start = cu[b], len = cu[b + 1] - start;
+    if (q0 >= len) return;
+    const int nt = (len + 15) >> 4;
+    const int np = (nt + 1) >> 1;
+    const int H3 = 3 * H;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int p = tid; p < np * 32 * 8; p += 256) {
+        const int row = p >> 3, s = p & 7;
+        half8 kv = zero8, vv = zero8;
+        if (row < len) {
+            const _Float16* src = qkv + (size_t)(start + row) * H3 + h * 64 + s * 8;
+            kv = *(const half8*)(src + H);
+            vv = *(const half8*)(src + 2 * H);
+        }
+        *(half8*)((char*)Ks + row * 128 + ((s ^ (row & 7)) << 4)) = kv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(s * 8 + j) * VS + row] = vv[j];
+    }
+    __syncthreads();
+    if (q0 + wave * 16 >= len) return;  // no barrier after this point
+
+    const int qi = q0 + wave * 16 + lr;
+    const bool qvalid = qi < len;
+    const int qrow = qvalid ? qi : len - 1;
+    half8 qf[2];
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const half8*)(qkv + (size_t)(start + qrow) * H3 + h * 64 + ds * 32 + g * 8);
+
+    // S^T tiles: lane holds keys 16t + 4g + r (r = 0..3) for query lr
+    f32x4 s[NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (t < nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) {
+                const half8 kf = *(const half8*)((const char*)Ks + (t * 16 + lr) * 128 + (((ds * 4 + g) ^ (lane & 7)) << 4));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ds], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = t * 16 + 4 * g + r;
+                s[t][r] = key < len ? acc[r] * 0.125f : -INFINITY;
+                mx = fmaxf(mx, s[t][r]);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = exp2f((s[t][r] - mx) * 1.4426950408889634f);
+                s[t][r] = e;
+                sum += e;
+            }
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.f / sum;
+
+    // O^T = V^T P^T. k-slot (g, j) of both operands <-> key 32pt + (j < 4 ? 4g + j : 16 + 4g + j - 4):
+    // the P operand is then exactly this lane's own S^T registers, no cross-lane traffic.
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pt = 0; pt < NT / 2; ++pt)
+        if (pt < np) {
+            half8 pf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pf[j] = (_Float16)(s[2 * pt][j] * inv);
+                pf[4 + j] = (2 * pt + 1 < nt) ? (_Float16)(s[2 * pt + 1][j] * inv) : (_Float16)0.f;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const _Float16* vp = Vt + (dt * 16 + lr) * VS + pt * 32 + 4 * g;
+                const half4 lo = *(const half4*)vp;
+                const half4 hi = *(const half4*)(vp + 16);
+                const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+            }
+        }
+    if (qvalid) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            half4 w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = (_Float16)o[dt][r];
+            *(half4*)(ctx + (size_t)(start + qi) * H + h * 64 + dt * 16 + 4 * g) = w;
+        }
+    }
+}
+
+template <int NT>
+constexpr int attention_lds_bytes() { return NT * 16 * 128 + 64 * (NT * 16 + 8) * 2; }
+
+}  // namespace
+}  // namespace mdr
+
+// ======================================================================================================
+// host side
+// ======================================================================================================
+using namespace mdr;
+
+struct mdr_encoder {
+    mdr_encoder_config cfg{};
+    int device = 0;
+    std::vector<void*> allocs;
+    float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
+    struct Layer {
+        _Float16 *wqkv, *wo, *w1, *w2;
+        float *bqkv, *bo, *b1, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    };
+    std::vector<Layer> layers;
+    _Float16* wproj = nullptr;
+    float *bproj = nullptr, *lnp_g = nullptr, *lnp_b = nullptr;
+};
+
+namespace {
+
+struct Workspace {
+    int *lens, *cu, *total, *tok_src, *tok_pid;
+    _Float16 *h16, *qkv, *ctx, *ffn, *cls16;
+    float *pre, *clspre;
+    size_t bytes;
+};
+
+Workspace carve(const mdr_encoder_config& c, int B, int L, char* base) {
+    Workspace w{};
+    size_t o = 0;
+    const size_t T = (size_t)B * L;
+    auto take = [&](size_t n) { size_t at = o; o += align_up(n, 256); return base ? base + at : (char*)nullptr; };
+    w.lens = (int*)take((size_t)B * 4);
+    w.cu = (int*)take((size_t)(B + 1) * 4);
+    w.total = (int*)take(4);
+    w.tok_src = (int*)take(T * 4);
+    w.tok_pid = (int*)take(T * 4);
+    w.h16 = (_Float16*)take(T * c.hidden * 2);
+    w.qkv = (_Float16*)take(T * 3 * c.hidden * 2);
+    w.ctx = (_Float16*)take(T * c.hidden * 2);
+    w.ffn = (_Float16*)take(T * c.ffn * 2);
+    w.pre = (float*)take(T * c.hidden * 4);
+    w.cls16 = (_Float16*)take((size_t)B * c.hidden * 2);
+    w.clspre = (float*)take((size_t)B * c.hidden * 4);
+    w.bytes = o + 256;
+    return w;
+}
+
+template <int EPI>
+int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
+                const _Float16* res, int ldr, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+        attr = true;
+    }
+    dim3 grid(N / BN, (M_cap + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm_f16_kernel<EPI>), grid, dim3(256), kGemmLds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
+template <int NT>
+int launch_attention(const _Float16* qkv, const int* cu, int B, int L, int H, int heads, _Float16* ctx, hipStream_t st) {
+    static bool attr = false;
+    constexpr int lds = attention_lds_bytes<NT>();
+    if (!attr) {
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)attention_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    dim3 grid((L + 63) / 64, heads, B);
+    hipLaunchKernelGGL((attention_kernel<NT>), grid, dim3(256), lds, st, qkv, cu, H, ctx);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
+const mdr_tensor* find_tensor(const mdr_tensor* ts, int n, const std::string& name) {
+    for (int i = 0; i < n; ++i)
+        if (ts[i].name && name == ts[i].name) return &ts[i];
+    return nullptr;
+}
+
+}  // namespace
 
 extern "C" {
-int mdr_encoder_create(const mdr_encoder_config*, const mdr_tensor*, int, int, int, void*, mdr_encoder**) {
-    return mdr::set_error(MDR_E_STATE, "encoder kernels not built yet");
+
+int mdr_encoder_create(const mdr_encoder_config* cfg, const mdr_tensor* tensors, int n_tensors, int weights_on_device, int device, void* stream,
+                       mdr_encoder** out) {
+    MDR_REQUIRE(cfg && tensors && out, "NULL argument");
+    MDR_REQUIRE(cfg->hidden > 0 && cfg->hidden % 128 == 0 && cfg->hidden <= 1024, "hidden=%d unsupported (multiple of 128, <= 1024)", cfg->hidden);
+    MDR_REQUIRE(cfg->heads > 0 && cfg->hidden == cfg->heads * 64, "head dim must be 64 (hidden=%d heads=%d)", cfg->hidden, cfg->heads);
+    MDR_REQUIRE(cfg->ffn > 0 && cfg->ffn % 128 == 0, "ffn=%d must be a multiple of 128", cfg->ffn);
+    MDR_REQUIRE(cfg->layers > 0 && cfg->vocab > 0 && cfg->max_pos > 2, "bad geometry");
+    int ndev = 0;
+    MDR_HIP_TRY(hipGetDeviceCount(&ndev));
+    MDR_REQUIRE(device >= 0 && device < ndev, "device %d out of range", device);
+    DeviceGuard guard(device);
+    hipStream_t st = (hipStream_t)stream;
+    mdr_encoder* h = new (std::nothrow) mdr_encoder();
+    MDR_REQUIRE(h != nullptr, "out of host memory");
+    h->cfg = *cfg;
+    h->device = device;
+    const int H = cfg->hidden, F = cfg->ffn;
+
+    float* staging = nullptr;
+    size_t staging_elems = (size_t)cfg->vocab * H;
+    if ((size_t)F * H > staging_elems) staging_elems = (size_t)F * H;
+    int rc = MDR_OK;
+    auto fail = [&](int code) {
+        if (staging) (void)hipFree(staging);
+        mdr_encoder_free(h);
+        return code;
+    };
+    if (hipMalloc((void**)&staging, staging_elems * 4) != hipSuccess) return fail(set_error(MDR_E_HIP, "hipMalloc(staging) failed"));
+
+    // fetch `name` (numel checked) into device fp32 memory at dst
+    auto fetch32 = [&](const std::string& name, size_t numel, float* dst) -> int {
+        const mdr_tensor* t = find_tensor(tensors, n_tensors, name);
+        if (!t) return set_error(MDR_E_INVALID, "missing key in state dict: %s", name.c_str());
+        if ((size_t)t->numel != numel) return set_error(MDR_E_INVALID, "size mismatch for %s: expected %zu elements, got %lld", name.c_str(), numel, (long long)t->numel);
+        MDR_HIP_TRY(hipMemcpyAsync(dst, t->data, numel * 4, weights_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        return MDR_OK;
+    };
+    auto alloc = [&](size_t bytes, void** p) -> int {
+        MDR_HIP_TRY(hipMalloc(p, bytes));
+        h->allocs.push_back(*p);
+        return MDR_OK;
+    };
+    auto keep32 = [&](const std::string& name, size_t numel, float** dst) -> int {
+        int r = alloc(numel * 4, (void**)dst);
+        if (r) return r;
+        return fetch32(name, numel, *dst);
+    };
+    // fp32 source -> fp16 at dst (dst already allocated)
+    auto to16 = [&](const std::string& name, size_t numel, _Float16* dst) -> int {
+        int r = fetch32(name, numel, staging);
+        if (r) return r;
+        hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, st, (const float*)staging, dst, (long long)numel);
+        MDR_HIP_TRY(hipGetLastError());
+        MDR_HIP_TRY(hipStreamSynchronize(st));  // staging is reused
+        return MDR_OK;
+    };
+#define MDR_TRY(expr) do { rc = (expr); if (rc) return fail(rc); } while (0)
+
+    const std::string E = "encoder.embeddings.";
+    MDR_TRY(keep32(E + "word_embeddings.weight", (size_t)cfg->vocab * H, &h->word));
+    MDR_TRY(keep32(E + "position_embeddings.weight", (size_t)cfg->max_pos * H, &h->pos));
+    MDR_TRY(keep32(E + "token_type_embeddings.weight", (size_t)H, &h->type0));  // row 0 of [type_vocab, H]; type_vocab == 1 for RoBERTa
+    MDR_TRY(keep32(E + "LayerNorm.weight", H, &h->emb_g));
+    MDR_TRY(keep32(E + "LayerNorm.bias", H, &h->emb_b));
+    h->layers.resize(cfg->layers);
+    for (int i = 0; i < cfg->layers; ++i) {
+        mdr_encoder::Layer& Ly = h->layers[i];
+        const std::string P = "encoder.encoder.layer." + std::to_string(i) + ".";
+        MDR_TRY(alloc((size_t)3 * H * H * 2, (void**)&Ly.wqkv));
+        MDR_TRY(alloc((size_t)3 * H * 4, (void**)&Ly.bqkv));
+        const char* qkv_names[3] = {"query", "key", "value"};
+        for (int j = 0; j < 3; ++j) {
+            MDR_TRY(to16(P + "attention.self." + qkv_names[j] + ".weight", (size_t)H * H, Ly.wqkv + (size_t)j * H * H));
+            MDR_TRY(fetch32(P + "attention.self." + qkv_names[j] + ".bias", H, Ly.bqkv + (size_t)j * H));
+        }
+        MDR_TRY(alloc((size_t)H * H * 2, (void**)&Ly.wo));
+        MDR_TRY(to16(P + "attention.output.dense.weight", (size_t)H * H, Ly.wo));
+        MDR_TRY(keep32(P + "attention.output.dense.bias", H, &Ly.bo));
+        MDR_TRY(keep32(P + "attention.output.LayerNorm.weight", H, &Ly.ln1_g));
+        MDR_TRY(keep32(P + "attention.output.LayerNorm.bias", H, &Ly.ln1_b));
+        MDR_TRY(alloc((size_t)F * H * 2, (void**)&Ly.w1));
+        MDR_TRY(to16(P + "intermediate.dense.weight", (size_t)F * H, Ly.w1));
+        MDR_TRY(keep32(P + "intermediate.dense.bias", F, &Ly.b1));
+        MDR_TRY(alloc((size_t)H * F * 2, (void**)&Ly.w2));
+        MDR_TRY(to16(P + "output.dense.weight", (size_t)H * F, Ly.w2));
+        MDR_TRY(keep32(P + "output.dense.bias", H, &Ly.b2));
+        MDR_TRY(keep32(P + "output.LayerNorm.weight", H, &Ly.ln2_g));
+        MDR_TRY(keep32(P + "output.LayerNorm.bias", H, &Ly.ln2_b));
+    }
+    MDR_TRY(alloc((size_t)H * H * 2, (void**)&h->wproj));
+    MDR_TRY(to16("project.0.weight", (size_t)H * H, h->wproj));
+    MDR_TRY(keep32("project.0.bias", H, &h->bproj));
+    MDR_TRY(keep32("project.1.weight", H, &h->lnp_g));
+    MDR_TRY(keep32("project.1.bias", H, &h->lnp_b));
+#undef MDR_TRY
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(set_error(MDR_E_HIP, "stream sync failed after weight upload"));
+    (void)hipFree(staging);
+    *out = h;
+    return MDR_OK;
 }
-int mdr_encoder_free(mdr_encoder*) { return MDR_OK; }
-size_t mdr_encoder_workspace_bytes(const mdr_encoder*, int, int) { return 0; }
-int mdr_encoder_forward(mdr_encoder*, const int64_t*, const int64_t*, int, int, float*, void*, size_t, void*) {
-    return mdr::set_error(MDR_E_STATE, "encoder kernels not built yet");
+
+int mdr_encoder_free(mdr_encoder* h) {
+    if (!h) return MDR_OK;
+    DeviceGuard guard(h->device);
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+    return MDR_OK;
 }
+
+size_t mdr_encoder_workspace_bytes(const mdr_encoder* h, int batch, int seq_len) {
+    if (!h || batch <= 0 || seq_len <= 0) return 0;
+    return carve(h->cfg, batch, seq_len, nullptr).bytes;
 }
+
+int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* mask_dev, int batch, int seq_len, float* out_dev, void* workspace_dev,
+                        size_t workspace_bytes, void* stream) {
+    MDR_REQUIRE(h != nullptr, "encoder handle is NULL");
+    MDR_REQUIRE(batch >= 0 && seq_len > 0, "bad shape batch=%d seq_len=%d", batch, seq_len);
+    if (batch == 0) return MDR_OK;
+    MDR_REQUIRE(ids_dev && mask_dev && out_dev, "NULL pointer");
+    MDR_REQUIRE(seq_len <= 512, "seq_len=%d exceeds 512 (RoBERTa has 514 positions)", seq_len);
+    MDR_REQUIRE((long long)batch * seq_len < (1ll << 31), "batch*seq_len overflows int32; split the batch");
+    const mdr_encoder_config& c = h->cfg;
+    const size_t need = carve(c, batch, seq_len, nullptr).bytes;
+    if (!workspace_dev || workspace_bytes < need) return set_error(MDR_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)(((uintptr_t)workspace_dev + 255) & ~(uintptr_t)255);
+    Workspace w = carve(c, batch, seq_len, base);
+    const int B = batch, L = seq_len, H = c.hidden, F = c.ffn;
+    const int Tcap = B * L;
+    const long long* ids = (const long long*)ids_dev;
+    const long long* mask = (const long long*)mask_dev;
+
+    hipLaunchKernelGGL(enc_lens_kernel, dim3((B + 3) / 4), dim3(256), 0, st, mask, B, L, w.lens);
+    hipLaunchKernelGGL(enc_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)w.lens, B, w.cu, w.total);
+    hipLaunchKernelGGL(enc_scatter_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, mask, B, L, c.pad_id, (const int*)w.cu, w.tok_src, w.tok_pid);
+    hipLaunchKernelGGL(embed_ln_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, ids, (const int*)w.tok_src, (const int*)w.tok_pid, (const int*)w.total,
+                       (const float*)h->word, (const float*)h->pos, (const float*)h->type0, (const float*)h->emb_g, (const float*)h->emb_b, H, c.vocab,
+                       c.max_pos, c.ln_eps, w.h16);
+    MDR_HIP_TRY(hipGetLastError());
+    int rc;
+    for (int i = 0; i < c.layers; ++i) {
+        const mdr_encoder::Layer& Ly = h->layers[i];
+        rc = launch_gemm<EPI_BIAS_F16>(w.h16, H, Ly.wqkv, Ly.bqkv, Tcap, w.total, 3 * H, H, w.qkv, 3 * H, nullptr, 0, st);
+        if (rc) return rc;
+        if (L <= 128) rc = launch_attention<8>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
+        else if (L <= 384) rc = launch_attention<24>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
+        else rc = launch_attention<32>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
+        if (rc) return rc;
+        rc = launch_gemm<EPI_BIAS_RES_F32>(w.ctx, H, Ly.wo, Ly.bo, Tcap, w.total, H, H, w.pre, H, w.h16, H, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(layernorm_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, (const float*)w.pre, Tcap, (const int*)w.total, H,
+                           (const float*)Ly.ln1_g, (const float*)Ly.ln1_b, c.ln_eps, w.h16, (float*)nullptr);
+        rc = launch_gemm<EPI_BIAS_GELU_F16>(w.h16, H, Ly.w1, Ly.b1, Tcap, w.total, F, H, w.ffn, F, nullptr, 0, st);
+        if (rc) return rc;
+        rc = launch_gemm<EPI_BIAS_RES_F32>(w.ffn, F, Ly.w2, Ly.b2, Tcap, w.total, H, F, w.pre, H, w.h16, H, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(layernorm_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, (const float*)w.pre, Tcap, (const int*)w.total, H,
+                           (const float*)Ly.ln2_g, (const float*)Ly.ln2_b, c.ln_eps, w.h16, (float*)nullptr);
+        MDR_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(gather_cls_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, (const _Float16*)w.h16, (const int*)w.cu, B, H, w.cls16);
+    rc = launch_gemm<EPI_BIAS_F32>(w.cls16, H, h->wproj, h->bproj, B, nullptr, H, H, w.clspre, H, nullptr, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, B, (const int*)nullptr, H, (const float*)h->lnp_g,
+                       (const float*)h->lnp_b, c.ln_eps, (_Float16*)nullptr, out_dev);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+"""Host-side mirror of the reference's encoder wrappers, backed by libmdrhip.so:
+
+    RobertaRetriever(config, args).encode_q(input_ids, mask, type_ids) -> [B, hidden]
+        /root/reference/mdr/retrieval/models/mhop_retriever.py:12-41
+    RobertaCtxEncoder(config, args)(batch)['embed']
+        /root/reference/mdr/retrieval/models/retriever.py:176-190
+    load_saved(model, path, exact=True)
+        /root/reference/mdr/retrieval/utils/utils.py:10-22
+    move_to_cuda(sample)
+        /root/reference/mdr/retrieval/utils/utils.py:24-41
+
+Same names, argument meaning and error behaviour, so the body of the reference's eval loop ports
+line for line. The arithmetic is not here: `load_state_dict` hands the fp32 tensors to
+mdr_encoder_create (csrc/mdr_encoder.hip) and `encode_seq` calls mdr_encoder_forward.
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+
+
+class RobertaConfig:
+    """The geometry constants of roberta-base. An HF config object works too:
+    only these attribute names are read."""
+
+    def __init__(self, vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                 max_position_embeddings=514, layer_norm_eps=1e-5, pad_token_id=1, **_):
+        self.vocab_size, self.hidden_size, self.num_hidden_layers = vocab_size, hidden_size, num_hidden_layers
+        self.num_attention_heads, self.intermediate_size = num_attention_heads, intermediate_size
+        self.max_position_embeddings, self.layer_norm_eps, self.pad_token_id = max_position_embeddings, layer_norm_eps, pad_token_id
+
+
+def expected_state_dict_shapes(config, with_pooler=True):
+    """Keys and shapes of the reference model's state_dict (HF RobertaModel + project head)."""
+    H, F = config.hidden_size, config.intermediate_size
+    sd = OrderedDict()
+    e = "encoder.embeddings."
+    sd[e + "word_embeddings.weight"] = (config.vocab_size, H)
+    sd[e + "position_embeddings.weight"] = (config.max_position_embeddings, H)
+    sd[e + "token_type_embeddings.weight"] = (1, H)
+    sd[e + "LayerNorm.weight"] = (H,)
+    sd[e + "LayerNorm.bias"] = (H,)
+    for i in range(config.num_hidden_layers):
+        p = f"encoder.encoder.layer.{i}."
+        for n in ("query", "key", "value"):
+            sd[p + f"attention.self.{n}.weight"] = (H, H)
+            sd[p + f"attention.self.{n}.bias"] = (H,)
+        sd[p + "attention.output.dense.weight"] = (H, H)
+        sd[p + "attention.output.dense.bias"] = (H,)
+        sd[p + "attention.output.LayerNorm.weight"] = (H,)
+        sd[p + "attention.output.LayerNorm.bias"] = (H,)
+        sd[p + "intermediate.dense.weight"] = (F, H)
+        sd[p + "intermediate.dense.bias"] = (F,)
+        sd[p + "output.dense.weight"] = (H, F)
+        sd[p + "output.dense.bias"] = (H,)
+        sd[p + "output.LayerNorm.weight"] = (H,)
+        sd[p + "output.LayerNorm.bias"] = (H,)
+    if with_pooler:
+        sd["encoder.pooler.dense.weight"] = (H, H)
+        sd["encoder.pooler.dense.bias"] = (H,)
+    sd["project.0.weight"] = (H, H)
+    sd["project.0.bias"] = (H,)
+    sd["project.1.weight"] = (H,)
+    sd["project.1.bias"] = (H,)
+    return sd
+
+
+class _HipRobertaEncoder:
+    """Shared implementation of the two reference classes (they compute the same function,
+    SURVEY.md §8a row a23)."""
+
+    MAX_TOKENS_PER_CALL = 1 << 17  # workspace bound: larger batches are encoded in slices
+
+    def __init__(self, config, args=None):
+        self.config = config
+        self.args = args
+        self._shapes = expected_state_dict_shapes(config)
+        self._h = ctypes.c_void_p()
+        self._ws = None
+        self.device = None
+        self.training = False
+
+    # -- nn.Module-like surface used by the reference scripts -------------------------------------------
+    def state_dict(self):
+        """Key set only (values are shapes): load_saved(exact=False) filters a checkpoint with it."""
+        return self._shapes
+
+    def load_state_dict(self, state_dict, strict=True):
+        missing = [k for k in self._shapes if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self._shapes]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: Missing key(s): {missing}. Unexpected key(s): {unexpected}.")
+        for k, shp in self._shapes.items():
+            if k in state_dict and tuple(state_dict[k].shape) != tuple(shp):
+                raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(state_dict[k].shape)} vs model {tuple(shp)}")
+        self._pending = {k: v for k, v in state_dict.items() if k in self._shapes}
+        if self.device is not None:
+            self._create()
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the encoder runs on a HIP device only (there is no CPU fallback)")
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        if getattr(self, "_pending", None) is not None:
+            self._create()
+        return self
+
+    def cuda(self):
+        return self.to("cuda")
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def half(self):  # apex-O1-equivalent numerics are built in
+        return self
+
+    # -- the forward ----------------------------------------------------------------------------------------
+    def encode_seq(self, input_ids, mask):
+        if not self._h.value:
+            raise RuntimeError("encoder has no weights on a device: call load_saved(...)/load_state_dict(...) and .to('cuda') first")
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        msk = mask.to(device=self.device, dtype=torch.int64).contiguous()
+        if ids.dim() != 2 or ids.shape != msk.shape:
+            raise ValueError(f"input_ids {tuple(ids.shape)} and mask {tuple(msk.shape)} must both be [B, L]")
+        B, L = ids.shape
+        out = torch.empty((B, self.config.hidden_size), dtype=torch.float32, device=self.device)
+        per = max(1, self.MAX_TOKENS_PER_CALL // L)
+        L_ = _lib.lib()
+        for lo in range(0, B, per):
+            hi = min(B, lo + per)
+            need = int(L_.mdr_encoder_workspace_bytes(self._h, hi - lo, L))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.check(L_.mdr_encoder_forward(self._h, ctypes.c_void_p(ids[lo:hi].data_ptr()), ctypes.c_void_p(msk[lo:hi].data_ptr()), hi - lo, L,
+                                              ctypes.c_void_p(out[lo:hi].data_ptr()), ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(),
+                                              _lib.current_stream_ptr(self.device)))
+        return out
+
+    # -- internals ----------------------------------------------------------------------------------------------
+    def _create(self):
+        sd = self._pending
+        cfg = _lib.EncoderConfig(self.config.vocab_size, self.config.hidden_size, self.config.num_hidden_layers, self.config.num_attention_heads,
+                                 self.config.intermediate_size, self.config.max_position_embeddings, self.config.pad_token_id,
+                                 float(self.config.layer_norm_eps))
+        names = [k for k in sd if "pooler" not in k]  # the pooler is never evaluated (`[0]` = sequence output)
+        on_dev = all(sd[k].is_cuda for k in names)
+        keep = []
+        arr = (_lib.Tensor * len(names))()
+        for i, k in enumerate(names):
+            t = sd[k].detach().to(dtype=torch.float32)
+            t = t.contiguous() if on_dev else t.cpu().contiguous()
+            keep.append(t)
+            arr[i] = _lib.Tensor(k.encode(), ctypes.c_void_p(t.data_ptr()), t.numel())
+        if self._h.value:
+            _lib.lib().mdr_encoder_free(self._h)
+            self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mdr_encoder_create(ctypes.byref(cfg), arr, len(names), int(on_dev), self.device.index,
+                                                     _lib.current_stream_ptr(self.device), ctypes.byref(self._h)))
+        self._pending = None
+
+    def __del__(self):
+        try:
+            if self._h.value:
+                _lib.lib().mdr_encoder_free(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    @classmethod
+    def random_init(cls, device, seed=0, config=None):
+        """Random weights of the right geometry (bench / smoke: no checkpoints offline)."""
+        config = config or RobertaConfig()
+        m = cls(config, None)
+        g = torch.Generator(device=device).manual_seed(seed)
+        sd = {}
+        for k, shp in m._shapes.items():
+            if k.endswith("LayerNorm.weight") or k == "project.1.weight":
+                sd[k] = 1.0 + 0.1 * torch.randn(shp, generator=g, device=device)
+            elif k.endswith("bias"):
+                sd[k] = 0.1 * torch.randn(shp, generator=g, device=device)
+            elif "embeddings" in k:
+                sd[k] = 0.5 * torch.randn(shp, generator=g, device=device)
+            else:
+                sd[k] = (1.5 / shp[1] ** 0.5) * torch.randn(shp, generator=g, device=device)
+        m.load_state_dict(sd)
+        return m.to(device).eval()
+
+
+class RobertaRetriever(_HipRobertaEncoder):
+    """mhop_retriever.py:12-41 -- query encoder; `encode_q(ids, mask, type_ids)` ignores type_ids like the reference."""
+
+    def encode_q(self, input_ids, q_mask, q_type_ids=None):
+        return self.encode_seq(input_ids, q_mask)
+
+    def __call__(self, batch):
+        raise NotImplementedError("training forward (six encode_seq calls, mhop_retriever.py:28-38) is outside the retrieval hot path")
+
+
+class RobertaCtxEncoder(_HipRobertaEncoder):
+    """retriever.py:176-190 -- passage encoder; `model(batch)` with keys input_ids / input_mask -> {'embed': ...}."""
+
+    def forward(self, batch):
+        return {"embed": self.encode_seq(batch["input_ids"], batch["input_mask"])}
+
+    __call__ = forward
+
+
+def load_saved(model, path, exact=True):
+    """utils.py:10-22 -- load a (possibly `module.`-prefixed) state dict; exact=False drops keys the model
+    does not have, then loads strictly (so a MISSING key still raises)."""
+    try:
+        state_dict = torch.load(path)
+    except Exception:
+        state_dict = torch.load(path, map_location=torch.device("cpu"))
+
+    def strip(k):
+        return k[7:] if k.startswith("module.") else k
+
+    known = model.state_dict()
+    if exact:
+        state_dict = {strip(k): v for k, v in state_dict.items()}
+    else:
+        state_dict = {strip(k): v for k, v in state_dict.items() if strip(k) in known}
+    model.load_state_dict(state_dict)
+    return model
+
+
+def move_to_cuda(sample):
+    """utils.py:24-41 -- recursive .cuda() over dicts / lists of tensors."""
+    if len(sample) == 0:
+        return {}
+
+    def mv(x):
+        if torch.is_tensor(x):
+            return x.cuda()
+        if isinstance(x, dict):
+            return {k: mv(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [mv(v) for v in x]
+        return x
+
+    return mv(sample)
+
+
+def smoke_check():
+    """Tiny-geometry encoder forward on cuda:0 against the numpy restatement (used by __graft_entry__.smoke)."""
+    import numpy as np
+    from oracle import roberta_oracle, seeded
+    geom = seeded.TINY
+    sd = seeded.make_state_dict(5, geom)
+    cfg = RobertaConfig(vocab_size=geom["vocab"], hidden_size=geom["hidden"], num_hidden_layers=geom["layers"],
+                        num_attention_heads=geom["heads"], intermediate_size=geom["ffn"])
+    m = RobertaRetriever(cfg, None)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.to("cuda:0")
+    ids, mask = seeded.make_token_batch(5, "smoke", 6, 40, geom["vocab"])
+    out = m.encode_q(torch.from_numpy(ids), torch.from_numpy(mask), None).cpu().numpy()
+    ref = roberta_oracle.encode(sd, geom, ids, mask, np.float64)
+    err = np.abs(out - ref).max()
+    assert err < 3e-2, f"encoder smoke mismatch: max abs err {err}"
+    return err
