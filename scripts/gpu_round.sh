@@ -19,17 +19,20 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 
 
 echo "== bench 1M (MIPS only)"
 timeout 600 python bench.py --rows 1000000 --steps 50 --warmup 5 --no-encoder --no-cpu-baseline $EXTRA > $OUT/bench_1m_mips.json 2> $OUT/bench_1m_mips.err; cat $OUT/bench_1m_mips.json; tail -3 $OUT/bench_1m_mips.err
-echo "== bench 5M (MIPS only, cpu baseline)"
-timeout 900 python bench.py --rows 5000000 --steps 20 --warmup 3 --no-encoder $EXTRA > $OUT/bench_5m_mips.json 2> $OUT/bench_5m_mips.err; cat $OUT/bench_5m_mips.json; tail -3 $OUT/bench_5m_mips.err
+echo "== bench 5M (MIPS only)"
+timeout 900 python bench.py --rows 5000000 --steps 20 --warmup 3 --no-encoder --no-cpu-baseline $EXTRA > $OUT/bench_5m_mips.json 2> $OUT/bench_5m_mips.err; cat $OUT/bench_5m_mips.json; tail -3 $OUT/bench_5m_mips.err
+echo "== bench DEFAULT (5M, 2-hop with encoder, cpu baseline) -- the headline line"
+timeout 900 python bench.py $EXTRA > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json; tail -3 $OUT/bench_default.err
 
-echo "== rocprofv3 kernel stats (5M, MIPS only)"
+echo "== rocprofv3 kernel stats (default bench command)"
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o mips5m -- python $REPO/bench.py --rows 5000000 --steps 10 --warmup 2 --no-encoder --no-cpu-baseline $EXTRA > $OUT/prof_stats.log 2>&1
-find $OUT/prof_stats -name "*kernel_stats*" | head -3
-S=$(find $OUT/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && head -12 "$S"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python $REPO/bench.py --no-cpu-baseline $EXTRA > $OUT/prof_stats.log 2>&1
+S=$(find $OUT/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && (cp "$S" $OUT/kernel_stats.csv; cut -c1-150 "$S" | head -14)
+rm -rf $OUT/prof_stats
 echo "== rocprofv3 pmc FETCH_SIZE (1M, MIPS only)"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_pmc -o mips1m -- python $REPO/bench.py --rows 1000000 --steps 3 --warmup 1 --no-encoder --no-cpu-baseline $EXTRA > $OUT/prof_pmc.log 2>&1
-P=$(find $OUT/prof_pmc -name "*counter_collection.csv" | head -1); [ -n "$P" ] && (head -1 "$P"; grep mips_stream "$P" | head -6)
+P=$(find $OUT/prof_pmc -name "*counter_collection.csv" | head -1); [ -n "$P" ] && (head -1 "$P" > $OUT/pmc_fetch_size.csv; grep mips_stream "$P" >> $OUT/pmc_fetch_size.csv; head -3 $OUT/pmc_fetch_size.csv | cut -c1-300)
+rm -rf $OUT/prof_pmc
 # keep the transfer small: drop the big traces, keep csv summaries
 find $OUT -name "*.db" -size +20M -delete 2>/dev/null
 du -sh $OUT

