@@ -531,6 +531,8 @@ int mdr_encoder_create(const mdr_encoder_config* cfg, const mdr_tensor* tensors,
     float* staging = nullptr;
     size_t staging_elems = (size_t)cfg->vocab * H;
     if ((size_t)F * H > staging_elems) staging_elems = (size_t)F * H;
+    if ((size_t)H * H > staging_elems) staging_elems = (size_t)H * H;
+    if ((size_t)cfg->max_pos * H > staging_elems) staging_elems = (size_t)cfg->max_pos * H;
     int rc = MDR_OK;
     auto fail = [&](int code) {
         if (staging) (void)hipFree(staging);

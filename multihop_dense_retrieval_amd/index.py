@@ -195,8 +195,10 @@ class ShardedIndexFlatIP:
         nq, k = Dt.shape
         # one packed buffer -> ONE collective per hop: scores as int32 bit patterns next to the ids
         packed = torch.stack([Dt.contiguous().view(torch.int32).to(torch.int64), It.contiguous()], 0)
-        gathered = torch.empty((self.world,) + tuple(packed.shape), dtype=torch.int64, device=packed.device)
+        # concatenated along dim 0 (the layout both gloo and RCCL accept), viewed as [world, 2, nq, k]
+        gathered = torch.empty((self.world * 2, nq, k), dtype=torch.int64, device=packed.device)
         self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        gathered = gathered.view(self.world, 2, nq, k)
         Dp = gathered[:, 0].to(torch.int32).view(torch.float32).reshape(self.world, nq, k)
         Ip = gathered[:, 1].reshape(self.world, nq, k)
         Dm, Im = self.merge_fn(Dp.contiguous(), Ip.contiguous())
