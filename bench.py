@@ -143,7 +143,8 @@ def main():
     achieved = stream_bytes / (search_ms * 1e-3) / 1e9 if search_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": local.last_kernel(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.pmc_traffic,
-                "algorithmic_bytes_per_launch": stream_bytes, "avg_launch_ms": round(search_ms, 4),
+                "algorithmic_bytes_per_launch": stream_bytes,
+                "designed_hbm_bytes_per_launch": stream_bytes // 2 if "screen" in local.last_kernel() else stream_bytes, "avg_launch_ms": round(search_ms, 4),
                 "launches_timed": pipe.search_calls_timed()}
 
     result = {

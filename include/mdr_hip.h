@@ -85,7 +85,8 @@ size_t mdr_index_search_workspace_bytes(const mdr_index* h, int nq, int k);
 int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_dev, int64_t* I_dev,
                      int64_t id_offset, void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* Test hook: force a kernel variant (0 = auto, 1 = generic fp32 reference kernel, 2 = MFMA stream). */
+/* Test hook: force a kernel variant (0 = auto, 1 = generic fp32 reference kernel, 2 = exact MFMA stream kernel,
+ * 3 = hi-plane screen + exact refinement, k == 1 only). */
 int mdr_index_set_variant(mdr_index* h, int variant);
 /* Name of the kernel the last search dispatched to (for rocprof matching); static storage. */
 const char* mdr_index_last_kernel(const mdr_index* h);

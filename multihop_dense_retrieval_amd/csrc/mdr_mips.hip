@@ -5,11 +5,20 @@
 //
 // Storage (MDR_STORE_F32X2H). Every fp32 element x is kept as an fp16 pair
 //     hi = fp16(x)            lo = fp16((x - hi) * 2^11)          x ~= hi + lo * 2^-11   (22-bit mantissa)
-// = 4 bytes per element, the same HBM bytes as fp32, laid out in MFMA-operand order so that the
-// search kernel's HBM->LDS DMA and its LDS->register reads are both perfectly linear:
-//     row-block rb (16 rows) -> k-block kb (32 columns) -> plane {hi,lo} -> 1 KiB fragment block
+// = 4 bytes per element, the same HBM bytes as fp32, kept as TWO planes (all hi, all lo), each laid out
+// in MFMA-operand order so that the HBM->LDS DMA and the LDS->register reads are perfectly linear:
+//     plane -> row-block rb (16 rows) -> k-block kb (32 columns) -> 1 KiB fragment block
 //     fragment block: lane l = (row & 15) + 16 * ((col & 31) >> 3) holds 8 consecutive columns (16 B)
 // which is exactly the A/B operand layout of v_mfma_f32_16x16x32_f16.
+//
+// Search, k == 1, nq <= 128 per pass ("screen" kernel, the headline path): only the HI plane is
+// streamed (2 bytes/element) and scored with ONE fp16 MFMA per k-block,  s_hi = qh.xh.  For every
+// (q, x):  |q.x - qh.xh| <= B_q = 1.2e-3 * |q| * max_row|x|   (fp16 rounding of both operands, 2^-10,
+// plus fp32 accumulation slack), so a row can only be the winner if  s_hi >= (largest s_hi seen) - 2 B_q.
+// Those few rows (a handful per query: the running maxima and near-ties) are appended to a candidate
+// list and re-scored exactly from both planes by mips_refine_kernel; if the list overflows (pathological
+// all-ties corpora) a flag makes the exact 3-MFMA stream kernel below run instead. Results are identical
+// to scoring every row exactly; HBM traffic is half the fp32 matrix.
 //
 // Search, nq <= 128 per pass ("stream" kernel): one 512-thread workgroup per CU, persistent over
 // row-blocks. Wave w keeps the (hi, lo) fragments of queries 16w..16w+15 for ALL of K in registers
@@ -64,7 +73,7 @@ __host__ __device__ inline unsigned key_row(u64 k) { return 0xFFFFFFFFu - (unsig
 __host__ __device__ inline size_t frag_offset(long long row, int col, int nkb) {
     long long rb = row >> 4;
     int rr = (int)(row & 15), kb = col >> 5, g = (col & 31) >> 3, j = col & 7;
-    return (size_t)rb * ((size_t)nkb * 2 * kFragBytes) + (size_t)kb * 2 * kFragBytes + (size_t)(rr + 16 * g) * 16 + (size_t)j * 2;
+    return (size_t)rb * ((size_t)nkb * kFragBytes) + (size_t)kb * kFragBytes + (size_t)(rr + 16 * g) * 16 + (size_t)j * 2;  // within one plane
 }
 
 // ---- conversion: row-major {f32,bf16,f16} -> fragment-tiled (hi, lo) fp16 -------------------------
@@ -83,7 +92,8 @@ __device__ inline float load_as_f32<_Float16>(const _Float16* p) { return (float
 // one thread per (row, 8-column group); rows [n_valid, n_total) are written as zeros (padding)
 template <typename T>
 __global__ void __launch_bounds__(256) convert_to_frag_kernel(const T* __restrict__ src, long long n_valid, long long n_total,
-                                                              int d, long long row0, char* __restrict__ dst, int* __restrict__ flags) {
+                                                              int d, long long row0, char* __restrict__ dst_hi, char* __restrict__ dst_lo,
+                                                              int* __restrict__ flags) {
     const int gpr = d >> 3;
     const int nkb = d >> 5;
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,8 +119,35 @@ __global__ void __launch_bounds__(256) convert_to_frag_kernel(const T* __restric
     }
     if (bad) atomicOr(flags, 1);
     size_t off = frag_offset(row0 + r, gi * 8, nkb);
-    *(half8*)(dst + off) = h;
-    *(half8*)(dst + off + kFragBytes) = l;
+    *(half8*)(dst_hi + off) = h;
+    *(half8*)(dst_lo + off) = l;
+}
+
+// one wave per row: flags[2] (as float bits) = max over rows of sum(x^2)   (non-negative floats order like ints)
+template <typename T>
+__global__ void __launch_bounds__(256) row_norm2_max_kernel(const T* __restrict__ src, long long n, int d, int* __restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) { float x = load_as_f32<T>(src + r * (long long)d + c); s += x * x; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0 && s == s) atomicMax(flags + 2, __float_as_int(s));
+}
+
+// one wave per query: bound[q] = c * |q| * max_row|x| + eps  (0 for padding queries)
+__global__ void __launch_bounds__(256) query_bound_kernel(const float* __restrict__ q, int nq, int nq_pad, int d, const int* __restrict__ flags,
+                                                          float* __restrict__ bound) {
+    const int lane = threadIdx.x & 63;
+    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nq_pad) return;
+    float s = 0.f;
+    if (i < nq)
+        for (int c = lane; c < d; c += 64) { float x = q[(size_t)i * d + c]; s += x * x; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) bound[i] = i < nq ? 1.2e-3f * sqrtf(s) * sqrtf(__int_as_float(flags[2])) * 1.0001f + 1e-4f : 0.f;
 }
 
 // ---- wave-level candidate list maintenance -----------------------------------------------------------
@@ -186,19 +223,26 @@ __device__ __forceinline__ void consider(float s, unsigned row, bool valid, floa
 #define MDR_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define MDR_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// DMA one row-block (hi plane then lo plane, NKB KiB each) into an LDS slot: 2*NKB pieces over 8 waves
 template <int NKB>
-__device__ __forceinline__ void issue_row_block(const char* __restrict__ X, int rb, char* slot, int wave, int lane) {
-    constexpr int CPW = NKB / 4;  // 1 KiB pieces per wave: 2*NKB pieces over 8 waves
-    const char* g = X + (size_t)rb * ((size_t)NKB * 2 * kFragBytes) + (size_t)(wave * CPW) * kFragBytes + lane * 16;
-    char* l = slot + wave * CPW * kFragBytes;
+__device__ __forceinline__ void issue_row_block(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int rb, char* slot, int wave, int lane) {
+    constexpr int CPW = NKB / 4;
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) __builtin_amdgcn_global_load_lds(MDR_GPTR(g + c * kFragBytes), MDR_LPTR(l + c * kFragBytes), 16, 0, 0);
+    for (int c = 0; c < CPW; ++c) {
+        const int piece = wave * CPW + c;  // wave-uniform
+        const char* plane = piece < NKB ? Xhi : Xlo;
+        const int kb = piece < NKB ? piece : piece - NKB;
+        const char* g = plane + ((size_t)rb * NKB + kb) * kFragBytes + lane * 16;
+        __builtin_amdgcn_global_load_lds(MDR_GPTR(g), MDR_LPTR(slot + piece * kFragBytes), 16, 0, 0);
+    }
 }
 
 template <int NKB, int KMODE>  // KMODE 0: k == 1 (register argmax)   1: 2 <= k <= 128 (candidate lists)
 __global__ void __launch_bounds__(512, 2)
-mips_stream_kernel(const char* __restrict__ X, long long n_rows, int n_rb, const char* __restrict__ Qf, int nq,
-                   u64* __restrict__ best, u64* __restrict__ cand, int* __restrict__ cand_cnt, u64* __restrict__ cand_kth, int k) {
+mips_stream_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, long long n_rows, int n_rb, const char* __restrict__ Qhi,
+                   const char* __restrict__ Qlo, int nq, u64* __restrict__ best, u64* __restrict__ cand, int* __restrict__ cand_cnt,
+                   u64* __restrict__ cand_kth, int k, const int* __restrict__ run_if) {
+    if (run_if && *run_if == 0) return;  // speculative screen pass succeeded: nothing to do
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int RB_BYTES = NKB * 2 * kFragBytes;
     constexpr int CPW = NKB / 4;
@@ -213,18 +257,18 @@ mips_stream_kernel(const char* __restrict__ X, long long n_rows, int n_rb, const
     }
 
     // start the corpus stream before anything else
-    if (n_my > 0) issue_row_block<NKB>(X, b, lds, wave, lane);
-    if (n_my > 1) issue_row_block<NKB>(X, b + G, lds + RB_BYTES, wave, lane);
+    if (n_my > 0) issue_row_block<NKB>(Xhi, Xlo, b, lds, wave, lane);
+    if (n_my > 1) issue_row_block<NKB>(Xhi, Xlo, b + G, lds + RB_BYTES, wave, lane);
 
     // this wave's queries: B operand fragments for all of K, resident for the whole kernel
     const bool wave_active = wave * 16 < nq;
     half8 qh[NKB], ql[NKB];
     {
-        const char* qp = Qf + (size_t)wave * RB_BYTES + lane * 16;
+        const size_t qoff = (size_t)wave * NKB * kFragBytes + lane * 16;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            qh[kb] = *(const half8*)(qp + kb * 2 * kFragBytes);
-            ql[kb] = *(const half8*)(qp + kb * 2 * kFragBytes + kFragBytes);
+            qh[kb] = *(const half8*)(Qhi + qoff + kb * kFragBytes);
+            ql[kb] = *(const half8*)(Qlo + qoff + kb * kFragBytes);
         }
         // Make the compiler retire these loads HERE: if they were still pending (in its scoreboard) at
         // loop entry it would put an s_waitcnt vmcnt(0) in front of the first MFMA of every iteration
@@ -257,7 +301,7 @@ mips_stream_kernel(const char* __restrict__ X, long long n_rows, int n_rb, const
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + 2 < n_my) issue_row_block<NKB>(X, b + (it + 2) * G, lds + ((it + 2) % 3) * RB_BYTES, wave, lane);
+        if (it + 2 < n_my) issue_row_block<NKB>(Xhi, Xlo, b + (it + 2) * G, lds + ((it + 2) % 3) * RB_BYTES, wave, lane);
 
         if (wave_active) {
             const char* p = lds + (it % 3) * RB_BYTES + lane * 16;
@@ -267,15 +311,15 @@ mips_stream_kernel(const char* __restrict__ X, long long n_rows, int n_rb, const
             half8 xh[PF], xl[PF];
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
-                xh[i] = *(const half8*)(p + i * 2 * kFragBytes);
-                xl[i] = *(const half8*)(p + i * 2 * kFragBytes + kFragBytes);
+                xh[i] = *(const half8*)(p + i * kFragBytes);
+                xl[i] = *(const half8*)(p + (NKB + i) * kFragBytes);
             }
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 const half8 ch = xh[kb % PF], cl = xl[kb % PF];
                 if (kb + PF < NKB) {
-                    xh[kb % PF] = *(const half8*)(p + (kb + PF) * 2 * kFragBytes);
-                    xl[kb % PF] = *(const half8*)(p + (kb + PF) * 2 * kFragBytes + kFragBytes);
+                    xh[kb % PF] = *(const half8*)(p + (kb + PF) * kFragBytes);
+                    xl[kb % PF] = *(const half8*)(p + (NKB + kb + PF) * kFragBytes);
                 }
                 aH = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, qh[kb], aH, 0, 0, 0);
                 aC1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, qh[kb], aC1, 0, 0, 0);
@@ -324,10 +368,171 @@ mips_stream_kernel(const char* __restrict__ X, long long n_rows, int n_rb, const
     }
 }
 
+// ---- the screen kernel (k == 1): hi plane only, one MFMA per k-block -------------------------------------
+// Stage = one "super-block" of 32 rows (2 row-blocks) of the hi plane = 2*NKB KiB; 3-slot ring as above.
+// Iteration 0 only samples (publishes the largest s_hi to gmax, emits nothing) so that the cut is tight
+// before candidates are emitted; its super-block is revisited as the last iteration.
+template <int NKB>
+__device__ __forceinline__ void issue_super_block(const char* __restrict__ Xhi, int sb, char* slot, int wave, int lane) {
+    constexpr int CPW = NKB / 4;  // 2*NKB pieces over 8 waves
+    const char* g = Xhi + ((size_t)sb * 2 * NKB + (size_t)wave * CPW) * kFragBytes + lane * 16;
+    char* l = slot + wave * CPW * kFragBytes;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) __builtin_amdgcn_global_load_lds(MDR_GPTR(g + c * kFragBytes), MDR_LPTR(l + c * kFragBytes), 16, 0, 0);
+}
+
+__device__ __forceinline__ unsigned load_u32_l2(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int NKB>
+__global__ void __launch_bounds__(512, 2)
+mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, const char* __restrict__ Qhi, const float* __restrict__ qbound, int nq,
+                   int q_base, unsigned* __restrict__ gmax /* [nq] ordered(max s_hi) */, u64* __restrict__ cand, int* __restrict__ cand_n,
+                   int cand_cap, int* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int SB_BYTES = 2 * NKB * kFragBytes;
+    constexpr int CPW = NKB / 4;
+    constexpr int HK = NKB / 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = gridDim.x, b = blockIdx.x;
+    const int n_my = (n_sb - b + G - 1) / G;  // >= 1 (grid <= n_sb)
+    const int n_it = n_my + 1;                // + the revisit of super-block 0
+    auto sb_of = [&](int it) { return b + (it == n_my ? 0 : it) * G; };
+
+    issue_super_block<NKB>(Xhi, sb_of(0), lds, wave, lane);
+    issue_super_block<NKB>(Xhi, sb_of(1), lds + SB_BYTES, wave, lane);
+
+    const bool wave_active = wave * 16 < nq;
+    half8 qh[NKB];
+    {
+        const size_t qoff = (size_t)wave * NKB * kFragBytes + lane * 16;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) qh[kb] = *(const half8*)(Qhi + qoff + kb * kFragBytes);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(qh[kb]));  // retire the loads before the loop (see stream kernel)
+    }
+    const int qlocal = wave * 16 + (lane & 15);
+    const bool q_valid = qlocal < nq;
+    const float band2 = q_valid ? 2.f * qbound[qlocal] : 0.f;
+    const unsigned sub_row = 4u * (unsigned)(lane >> 4);
+    float hmax = -FLT_MAX;       // largest s_hi this lane has seen
+    float known = -FLT_MAX;      // largest s_hi known for this query (lane, wave, or published by other workgroups)
+    float published = -FLT_MAX;  // what this wave last pushed to gmax (lanes 0..15 only)
+
+    for (int it = 0; it < n_it; ++it) {
+        if (it + 1 < n_it)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 2 < n_it) issue_super_block<NKB>(Xhi, sb_of(it + 2), lds + ((it + 2) % 3) * SB_BYTES, wave, lane);
+        if (!wave_active) continue;
+
+        const char* p = lds + (it % 3) * SB_BYTES + lane * 16;
+        // 4 independent accumulation chains: {row-block 0, 1} x {first, second half of K}; LDS reads run
+        // PF k-steps ahead of the MFMAs that consume them (issue order pinned below)
+        f32x4 a00 = {0.f, 0.f, 0.f, 0.f}, a01 = a00, a10 = a00, a11 = a00;
+        constexpr int PF = 2;
+        half8 x00[PF], x01[PF], x10[PF], x11[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            x00[i] = *(const half8*)(p + i * kFragBytes);
+            x01[i] = *(const half8*)(p + (HK + i) * kFragBytes);
+            x10[i] = *(const half8*)(p + (NKB + i) * kFragBytes);
+            x11[i] = *(const half8*)(p + (NKB + HK + i) * kFragBytes);
+        }
+#pragma unroll
+        for (int kb = 0; kb < HK; ++kb) {
+            const half8 c00 = x00[kb % PF], c01 = x01[kb % PF], c10 = x10[kb % PF], c11 = x11[kb % PF];
+            if (kb + PF < HK) {
+                x00[kb % PF] = *(const half8*)(p + (kb + PF) * kFragBytes);
+                x01[kb % PF] = *(const half8*)(p + (HK + kb + PF) * kFragBytes);
+                x10[kb % PF] = *(const half8*)(p + (NKB + kb + PF) * kFragBytes);
+                x11[kb % PF] = *(const half8*)(p + (NKB + HK + kb + PF) * kFragBytes);
+            }
+            a00 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c00, qh[kb], a00, 0, 0, 0);
+            a01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c01, qh[HK + kb], a01, 0, 0, 0);
+            a10 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c10, qh[kb], a10, 0, 0, 0);
+            a11 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c11, qh[HK + kb], a11, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * PF, 0);
+#pragma unroll
+        for (int kb = 0; kb < HK; ++kb) {
+            if (kb + PF < HK) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        const f32x4 s0 = a00 + a01, s1 = a10 + a11;
+        const unsigned row0 = (unsigned)sb_of(it) * 32u + sub_row;
+        const float cut = known - band2;  // a row below this cannot beat the row that produced `known`
+        const bool emit = it > 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = h ? s1[r] : s0[r];
+                const unsigned row = row0 + 16u * h + r;
+                if ((long long)row < n_rows && q_valid) {
+                    if (emit && sc >= cut) {
+                        int pos = atomicAdd(cand_n, 1);
+                        if (pos < cand_cap) cand[pos] = ((u64)(unsigned)(q_base + qlocal) << 32) | row;
+                        else *overflow = 1;
+                    }
+                    hmax = fmaxf(hmax, sc);
+                }
+            }
+        // share the maximum: 4 lanes per query, then (lanes 0..15) the other workgroups through gmax
+        float hm = fmaxf(hmax, __shfl_xor(hmax, 16));
+        hm = fmaxf(hm, __shfl_xor(hm, 32));
+        float kn = fmaxf(known, hm);
+        // Publishing is fire-and-forget, but READING gmax is a VMEM load the compiler waits for with vmcnt(0),
+        // which also drains the in-flight corpus DMA; so refresh on a geometric schedule (it = 1,2,3,4,6,8,12,16,..):
+        // the expected number of extra candidates per query stays O(1) per interval (harmonic argument).
+        const bool refresh = it < 4 || ((it & (it - 1)) == 0) || (((it / 3) & (it / 3 - 1)) == 0 && it % 3 == 0);
+        if (refresh) {
+            if (lane < 16 && q_valid) {
+                if (hm > published) { atomicMax(gmax + qlocal, ord32(hm)); published = hm; }
+                unsigned g = load_u32_l2(gmax + qlocal);
+                if (g) kn = fmaxf(kn, unord32(g));
+            }
+            kn = __shfl(kn, lane & 15);
+        }
+        known = kn;
+    }
+}
+
+// exact re-scoring of the screen kernel's candidates: one wave per (query, row), fp32 FMA on both planes
+__global__ void __launch_bounds__(256)
+mips_refine_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, const u64* __restrict__ cand,
+                   const int* __restrict__ cand_n, int cand_cap, u64* __restrict__ best) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int n = min(*cand_n, cand_cap);
+    const int d = nkb * 32;
+    for (int c = blockIdx.x * wpb + (threadIdx.x >> 6); c < n; c += gridDim.x * wpb) {
+        const u64 e = cand[c];
+        const unsigned qi = (unsigned)(e >> 32), row = (unsigned)e;
+        const size_t base = ((size_t)(row >> 4) * nkb) * kFragBytes + (size_t)(row & 15) * 16;
+        float acc = 0.f;
+        for (int pc = lane; pc < nkb * 4; pc += 64) {  // piece = (k-block, 8-column group)
+            const int kb = pc >> 2, g = pc & 3;
+            const size_t off = base + (size_t)kb * kFragBytes + (size_t)g * 256;
+            const half8 h = *(const half8*)(Xhi + off);
+            const half8 l = *(const half8*)(Xlo + off);
+            const float* qp = q + (size_t)qi * d + kb * 32 + g * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf((float)h[j] + (float)l[j] * kLoInv, qp[j], acc);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) atomicMax(best + qi, make_key(acc, row));
+    }
+}
+
 // ---- generic kernel: any d (multiple of 32), fp32 FMA on the reconstructed values ------------------
 // Correctness reference on the device and fallback for shapes the stream kernel does not cover.
 __global__ void __launch_bounds__(256)
-mips_generic_kernel(const char* __restrict__ X, long long n_rows, int n_rb, int nkb, const float* __restrict__ q, int nq,
+mips_generic_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, long long n_rows, int n_rb, int nkb, const float* __restrict__ q, int nq,
                     u64* __restrict__ cand, int* __restrict__ cand_cnt, u64* __restrict__ cand_kth, int k) {
     __shared__ int lds_cnt[kGenericQ];
     const int lane = threadIdx.x & 63;
@@ -343,10 +548,10 @@ mips_generic_kernel(const char* __restrict__ X, long long n_rows, int n_rb, int 
     float tau = -INFINITY;
     u64* wave_lists = cand + ((size_t)blockIdx.x * kGenericQ + (size_t)wave * 16) * kGenericCap;
     u64* my_list = wave_lists + (size_t)(lane & 15) * kGenericCap;
-    const size_t rb_bytes = (size_t)nkb * 2 * kFragBytes;
+    const size_t rb_bytes = (size_t)nkb * kFragBytes;
     if (wave_active) {
         for (int rb = blockIdx.x; rb < n_rb; rb += gridDim.x) {
-            const char* blk = X + (size_t)rb * rb_bytes;
+            const size_t blk = (size_t)rb * rb_bytes;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             for (int kb = 0; kb < nkb; ++kb) {
                 for (int gp = 0; gp < 4; ++gp) {
@@ -355,9 +560,9 @@ mips_generic_kernel(const char* __restrict__ X, long long n_rows, int n_rb, int 
                     for (int j = 0; j < 8; ++j) qv[j] = qp[kb * 32 + gp * 8 + j];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const char* e = blk + (size_t)kb * 2 * kFragBytes + (size_t)((4 * g4 + r) + 16 * gp) * 16;
-                        half8 h = *(const half8*)e;
-                        half8 l = *(const half8*)(e + kFragBytes);
+                        const size_t e = blk + (size_t)kb * kFragBytes + (size_t)((4 * g4 + r) + 16 * gp) * 16;
+                        half8 h = *(const half8*)(Xhi + e);
+                        half8 l = *(const half8*)(Xlo + e);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) acc[r] = fmaf((float)h[j] + (float)l[j] * kLoInv, qv[j], acc[r]);
                     }
@@ -542,9 +747,10 @@ struct mdr_index {
     int d = 0, nkb = 0, storage = 0, device = 0;
     int num_cus = 256;
     long long ntotal = 0;
-    long long cap_rows = 0;  // multiple of 16
-    char* data = nullptr;    // fragment-tiled shard
-    int* flags = nullptr;    // device int: bit0 = range error seen by a conversion
+    long long cap_rows = 0;  // multiple of 32 (one screen-kernel super-block)
+    char* hi = nullptr;      // fragment-tiled planes, cap_rows * d * 2 bytes each
+    char* lo = nullptr;
+    int* flags = nullptr;    // device ints: [0] range error seen by add(), [1] same for queries (ignored), [2] max row |x|^2 (float bits)
     void* stage = nullptr;   // device staging for host-sourced add()
     size_t stage_bytes = 0;
     int variant = 0;
@@ -553,44 +759,62 @@ struct mdr_index {
 
 namespace {
 
-size_t bytes_per_row(const mdr_index* h) { return (size_t)h->d * 4; }
+constexpr int kCandCap = 1 << 20;  // (query,row) candidates the screen kernel may emit per pass before falling back
+
+size_t plane_bytes_per_row(const mdr_index* h) { return (size_t)h->d * 2; }
+long long pad32(long long n) { return (n + 31) / 32 * 32; }
 
 int grow(mdr_index* h, long long need_rows, hipStream_t st) {
-    long long need = (need_rows + 15) / 16 * 16;
+    long long need = pad32(need_rows);
     if (need <= h->cap_rows) return MDR_OK;
     long long ncap = need;  // first reservation is exact; later ones grow by 1.5x
     if (h->cap_rows) {
-        long long geo = (h->cap_rows + h->cap_rows / 2 + 15) / 16 * 16;
+        long long geo = pad32(h->cap_rows + h->cap_rows / 2);
         if (geo > ncap) ncap = geo;
     }
-    char* nd = nullptr;
-    MDR_HIP_TRY(hipMalloc((void**)&nd, (size_t)ncap * bytes_per_row(h)));
-    size_t used = (size_t)((h->ntotal + 15) / 16 * 16) * bytes_per_row(h);
-    if (used) MDR_HIP_TRY(hipMemcpyAsync(nd, h->data, used, hipMemcpyDeviceToDevice, st));
-    MDR_HIP_TRY(hipMemsetAsync(nd + used, 0, (size_t)ncap * bytes_per_row(h) - used, st));
+    const size_t nbytes = (size_t)ncap * plane_bytes_per_row(h);
+    const size_t used = (size_t)pad32(h->ntotal) * plane_bytes_per_row(h);
+    char* planes[2] = {nullptr, nullptr};
+    char* old[2] = {h->hi, h->lo};
+    for (int i = 0; i < 2; ++i) {
+        MDR_HIP_TRY(hipMalloc((void**)&planes[i], nbytes));
+        if (used) MDR_HIP_TRY(hipMemcpyAsync(planes[i], old[i], used, hipMemcpyDeviceToDevice, st));
+        MDR_HIP_TRY(hipMemsetAsync(planes[i] + used, 0, nbytes - used, st));
+    }
     MDR_HIP_TRY(hipStreamSynchronize(st));
-    if (h->data) MDR_HIP_TRY(hipFree(h->data));
-    h->data = nd;
+    for (int i = 0; i < 2; ++i)
+        if (old[i]) MDR_HIP_TRY(hipFree(old[i]));
+    h->hi = planes[0];
+    h->lo = planes[1];
     h->cap_rows = ncap;
     return MDR_OK;
 }
 
 template <typename T>
-int launch_convert(const T* src_dev, long long n_valid, long long n_total, int d, long long row0, char* dst, int* flags, hipStream_t st) {
+int launch_convert(const T* src_dev, long long n_valid, long long n_total, int d, long long row0, char* dst_hi, char* dst_lo, int* flags,
+                   hipStream_t st) {
     long long threads = n_total * (d / 8);
     if (threads == 0) return MDR_OK;
     long long blocks = (threads + 255) / 256;
-    hipLaunchKernelGGL(convert_to_frag_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, src_dev, n_valid, n_total, d, row0, dst, flags);
+    hipLaunchKernelGGL(convert_to_frag_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, src_dev, n_valid, n_total, d, row0, dst_hi, dst_lo, flags);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }
 
-int convert_any(const void* src_dev, int dtype, long long n_valid, long long n_total, int d, long long row0, char* dst, int* flags,
-                hipStream_t st) {
+template <typename T>
+int launch_add(mdr_index* h, const T* src_dev, long long n, long long row0, hipStream_t st) {
+    int rc = launch_convert(src_dev, n, n, h->d, row0, h->hi, h->lo, h->flags, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(row_norm2_max_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src_dev, n, h->d, h->flags);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
+int add_any(mdr_index* h, const void* src_dev, int dtype, long long n, long long row0, hipStream_t st) {
     switch (dtype) {
-        case MDR_DT_F32: return launch_convert((const float*)src_dev, n_valid, n_total, d, row0, dst, flags, st);
-        case MDR_DT_BF16: return launch_convert((const unsigned short*)src_dev, n_valid, n_total, d, row0, dst, flags, st);
-        case MDR_DT_F16: return launch_convert((const _Float16*)src_dev, n_valid, n_total, d, row0, dst, flags, st);
+        case MDR_DT_F32: return launch_add(h, (const float*)src_dev, n, row0, st);
+        case MDR_DT_BF16: return launch_add(h, (const unsigned short*)src_dev, n, row0, st);
+        case MDR_DT_F16: return launch_add(h, (const _Float16*)src_dev, n, row0, st);
         default: return set_error(MDR_E_INVALID, "unknown src_dtype %d", dtype);
     }
 }
@@ -598,44 +822,55 @@ int convert_any(const void* src_dev, int dtype, long long n_valid, long long n_t
 size_t elem_size(int dtype) { return dtype == MDR_DT_F32 ? 4 : 2; }
 
 bool stream_kernel_supports(const mdr_index* h, int k) { return h->d == 768 && k <= 128; }
+bool screen_kernel_supports(const mdr_index* h, int k) { return h->d == 768 && k == 1; }
+
+enum Path { PATH_GENERIC = 1, PATH_STREAM = 2, PATH_SCREEN = 3 };
 
 struct SearchPlan {
-    bool stream;
-    int qgroup;      // queries per pass
-    int cap;         // candidate slots per (wg, query)
-    int G;           // workgroups
-    size_t off_qfrag, off_best, off_cand, off_cnt, off_kth, total;
+    int path;
+    int qgroup;  // queries per pass
+    int cap;     // candidate slots per (wg, query) of the list-based kernels
+    int G;       // workgroups
+    size_t off_qhi, off_qlo, off_bound, off_best, off_gmax, off_scand, off_sctl, off_cand, off_cnt, off_kth, total;
 };
 
 SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     SearchPlan p{};
-    int variant = h->variant;
-    p.stream = (variant == 2) || (variant == 0 && stream_kernel_supports(h, k));
-    if (p.stream && !stream_kernel_supports(h, k)) p.stream = false;
-    long long n_rb = (h->ntotal + 15) / 16;
-    if (p.stream) {
+    const int v = h->variant;
+    if (v == PATH_GENERIC) p.path = PATH_GENERIC;
+    else if (v == PATH_STREAM) p.path = stream_kernel_supports(h, k) ? PATH_STREAM : PATH_GENERIC;
+    else if (screen_kernel_supports(h, k)) p.path = PATH_SCREEN;       // auto or forced screen
+    else if (stream_kernel_supports(h, k)) p.path = PATH_STREAM;
+    else p.path = PATH_GENERIC;
+    const long long n_rb = (h->ntotal + 15) / 16;
+    if (p.path != PATH_GENERIC) {
         p.qgroup = kStreamQ;
         p.cap = kStreamCap;
-        p.G = (int)(n_rb < h->num_cus ? (n_rb > 0 ? n_rb : 1) : h->num_cus);
+        long long units = p.path == PATH_SCREEN ? (h->ntotal + 31) / 32 : n_rb;
+        p.G = (int)(units < h->num_cus ? (units > 0 ? units : 1) : h->num_cus);
     } else {
         p.qgroup = kGenericQ;
         p.cap = kGenericCap;
         long long g = (long long)h->num_cus * 2;
         p.G = (int)(n_rb < g ? (n_rb > 0 ? n_rb : 1) : g);
     }
-    int ngroups = (nq + p.qgroup - 1) / p.qgroup;
+    const int ngroups = (nq + p.qgroup - 1) / p.qgroup;
+    const size_t nq_pad = (size_t)ngroups * p.qgroup;
+    const bool frag = p.path != PATH_GENERIC;
+    const bool lists = !(p.path == PATH_SCREEN || (p.path == PATH_STREAM && k == 1));
+    // the conditional exact pass behind the screen kernel needs the stream kernel's (k == 1) buffers only
     size_t o = 0;
-    p.off_qfrag = o;
-    o += align_up(p.stream ? (size_t)ngroups * p.qgroup * h->d * 4 : 0, 256);
-    p.off_best = o;
-    o += align_up((size_t)(nq > 0 ? nq : 1) * 8, 256);
-    bool lists = !(p.stream && k == 1);
-    p.off_cand = o;
-    o += align_up(lists ? (size_t)p.G * p.qgroup * p.cap * 8 : 0, 256);
-    p.off_cnt = o;
-    o += align_up(lists ? (size_t)p.G * p.qgroup * 4 : 0, 256);
-    p.off_kth = o;
-    o += align_up(lists ? (size_t)p.G * p.qgroup * 8 : 0, 256);
+    auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
+    p.off_qhi = take(frag ? nq_pad * h->d * 2 : 0);
+    p.off_qlo = take(frag ? nq_pad * h->d * 2 : 0);
+    p.off_bound = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
+    p.off_best = take((size_t)(nq > 0 ? nq : 1) * 8);
+    p.off_gmax = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
+    p.off_scand = take(p.path == PATH_SCREEN ? (size_t)kCandCap * 8 : 0);
+    p.off_sctl = take(p.path == PATH_SCREEN ? 256 : 0);  // [0] candidate count, [1] overflow flag
+    p.off_cand = take(lists ? (size_t)p.G * p.qgroup * p.cap * 8 : 0);
+    p.off_cnt = take(lists ? (size_t)p.G * p.qgroup * 4 : 0);
+    p.off_kth = take(lists ? (size_t)p.G * p.qgroup * 8 : 0);
     p.total = o + 256;
     return p;
 }
@@ -672,7 +907,8 @@ int mdr_index_create(int d, int storage, int device, mdr_index** out) {
 int mdr_index_free(mdr_index* h) {
     if (!h) return MDR_OK;
     DeviceGuard g(h->device);
-    if (h->data) (void)hipFree(h->data);
+    if (h->hi) (void)hipFree(h->hi);
+    if (h->lo) (void)hipFree(h->lo);
     if (h->flags) (void)hipFree(h->flags);
     if (h->stage) (void)hipFree(h->stage);
     delete h;
@@ -681,7 +917,7 @@ int mdr_index_free(mdr_index* h) {
 
 int mdr_index_reserve(mdr_index* h, int64_t n_rows) {
     MDR_REQUIRE(h != nullptr, "index handle is NULL");
-    MDR_REQUIRE(n_rows >= 0 && n_rows < 0xFFFFFFF0ll, "n_rows out of range");
+    MDR_REQUIRE(n_rows >= 0 && n_rows < 0xFFFFFFE0ll, "n_rows out of range");
     DeviceGuard g(h->device);
     return grow(h, n_rows, nullptr);
 }
@@ -691,15 +927,18 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
     MDR_REQUIRE(n >= 0, "n < 0");
     MDR_REQUIRE(n == 0 || rows != nullptr, "rows is NULL");
     MDR_REQUIRE(src_dtype >= MDR_DT_F32 && src_dtype <= MDR_DT_F16, "unknown src_dtype %d", src_dtype);
-    MDR_REQUIRE(h->ntotal + n < 0xFFFFFFF0ll, "index would exceed 2^32-16 rows per shard");
+    MDR_REQUIRE(h->ntotal + n < 0xFFFFFFE0ll, "index would exceed 2^32-32 rows per shard");
     if (n == 0) return MDR_OK;
     DeviceGuard g(h->device);
     hipStream_t st = (hipStream_t)stream;
     int rc = grow(h, h->ntotal + n, st);
     if (rc) return rc;
+    int before[4] = {0, 0, 0, 0};
+    MDR_HIP_TRY(hipMemcpyAsync(before, h->flags, sizeof(before), hipMemcpyDeviceToHost, st));
+    MDR_HIP_TRY(hipStreamSynchronize(st));
     const size_t row_src = (size_t)h->d * elem_size(src_dtype);
     if (rows_on_device) {
-        rc = convert_any(rows, src_dtype, n, n, h->d, h->ntotal, h->data, h->flags, st);
+        rc = add_any(h, rows, src_dtype, n, h->ntotal, st);
         if (rc) return rc;
     } else {
         // chunked H2D through a device staging buffer (<= 256 MiB), converting straight into the shard
@@ -715,7 +954,7 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
         for (long long r0 = 0; r0 < n; r0 += chunk_rows) {
             long long nr = n - r0 < chunk_rows ? n - r0 : chunk_rows;
             MDR_HIP_TRY(hipMemcpyAsync(h->stage, (const char*)rows + (size_t)r0 * row_src, (size_t)nr * row_src, hipMemcpyHostToDevice, st));
-            rc = convert_any(h->stage, src_dtype, nr, nr, h->d, h->ntotal + r0, h->data, h->flags, st);
+            rc = add_any(h, h->stage, src_dtype, nr, h->ntotal + r0, st);
             if (rc) return rc;
             MDR_HIP_TRY(hipStreamSynchronize(st));  // staging buffer is reused; host buffer must be consumed before return
         }
@@ -724,7 +963,9 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
     MDR_HIP_TRY(hipMemcpyAsync(&flag, h->flags, sizeof(int), hipMemcpyDeviceToHost, st));
     MDR_HIP_TRY(hipStreamSynchronize(st));
     if (flag) {
-        MDR_HIP_TRY(hipMemsetAsync(h->flags, 0, sizeof(int), st));
+        // roll back: the rows stay invisible (ntotal unchanged), the norm bound returns to its previous value
+        MDR_HIP_TRY(hipMemcpyAsync(h->flags, before, sizeof(before), hipMemcpyHostToDevice, st));
+        MDR_HIP_TRY(hipStreamSynchronize(st));
         return set_error(MDR_E_RANGE, "add(): a value is non-finite or |x| > 32768, not representable in F32X2H storage; rows were not added");
     }
     h->ntotal += n;
@@ -733,11 +974,11 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
 
 int64_t mdr_index_ntotal(const mdr_index* h) { return h ? h->ntotal : 0; }
 int mdr_index_dim(const mdr_index* h) { return h ? h->d : 0; }
-int64_t mdr_index_stream_bytes(const mdr_index* h) { return h ? (int64_t)((h->ntotal + 15) / 16 * 16) * (int64_t)bytes_per_row(h) : 0; }
+int64_t mdr_index_stream_bytes(const mdr_index* h) { return h ? (int64_t)((h->ntotal + 15) / 16 * 16) * (int64_t)h->d * 4 : 0; }
 
 int mdr_index_set_variant(mdr_index* h, int variant) {
     MDR_REQUIRE(h != nullptr, "index handle is NULL");
-    MDR_REQUIRE(variant >= 0 && variant <= 2, "variant must be 0 (auto), 1 (generic) or 2 (stream)");
+    MDR_REQUIRE(variant >= 0 && variant <= 3, "variant must be 0 (auto), 1 (generic), 2 (exact stream) or 3 (screen + refine)");
     h->variant = variant;
     return MDR_OK;
 }
@@ -756,8 +997,10 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
     MDR_REQUIRE(k >= 1 && k <= kKMax, "k=%d out of range [1, %d]", k, kKMax);
     if (nq == 0) return MDR_OK;
     MDR_REQUIRE(q_dev && D_dev && I_dev, "NULL query/result pointer");
-    if (h->variant == 2 && !stream_kernel_supports(h, k))
+    if (h->variant == PATH_STREAM && !stream_kernel_supports(h, k))
         return set_error(MDR_E_INVALID, "stream kernel forced but unsupported for d=%d k=%d (needs d=768, k<=128)", h->d, k);
+    if (h->variant == PATH_SCREEN && !screen_kernel_supports(h, k))
+        return set_error(MDR_E_INVALID, "screen kernel forced but unsupported for d=%d k=%d (needs d=768, k=1)", h->d, k);
     DeviceGuard g(h->device);
     hipStream_t st = (hipStream_t)stream;
     if (h->ntotal == 0) {
@@ -772,49 +1015,81 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
         return set_error(MDR_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", p.total, workspace_bytes);
     char* ws = (char*)(((uintptr_t)workspace_dev + 255) & ~(uintptr_t)255);
     const int n_rb = (int)((h->ntotal + 15) / 16);
+    const int n_sb = (int)((h->ntotal + 31) / 32);
     u64* best = (u64*)(ws + p.off_best);
     u64* cand = (u64*)(ws + p.off_cand);
     int* cnt = (int*)(ws + p.off_cnt);
     u64* kth = (u64*)(ws + p.off_kth);
     const int ngroups = (nq + p.qgroup - 1) / p.qgroup;
+    constexpr int NKB = 24;
+    const size_t rb_bytes = (size_t)NKB * 2 * kFragBytes;  // one exact-kernel stage == one screen-kernel stage == 48 KiB
+    static bool attr_done[3] = {false, false, false};
 
-    if (p.stream) {
-        char* qfrag = ws + p.off_qfrag;
-        int rc = launch_convert(q_dev, (long long)nq, (long long)ngroups * p.qgroup, h->d, 0, qfrag, h->flags + 1, st);
+    if (p.path != PATH_GENERIC) {
+        char* qhi = ws + p.off_qhi;
+        char* qlo = ws + p.off_qlo;
+        int rc = launch_convert(q_dev, (long long)nq, (long long)ngroups * p.qgroup, h->d, 0, qhi, qlo, h->flags + 1, st);
         if (rc) return rc;
-        constexpr int NKB = 24;
-        const size_t rb_bytes = (size_t)NKB * 2 * kFragBytes;
-        const size_t lds_bytes = 3 * rb_bytes + (k == 1 ? 0 : kStreamQ * sizeof(int));
-        static bool attr_done[2] = {false, false};
+        const size_t qgroup_bytes = (size_t)p.qgroup * h->d * 2;
         if (k == 1) {
             if (!attr_done[0]) {
                 MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_stream_kernel<NKB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * rb_bytes)));
                 attr_done[0] = true;
             }
             MDR_HIP_TRY(hipMemsetAsync(best, 0, (size_t)nq * 8, st));
+            const int* run_if = nullptr;
+            if (p.path == PATH_SCREEN) {
+                if (!attr_done[2]) {
+                    MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screen_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * rb_bytes)));
+                    attr_done[2] = true;
+                }
+                float* bound = (float*)(ws + p.off_bound);
+                unsigned* gmax = (unsigned*)(ws + p.off_gmax);
+                u64* scand = (u64*)(ws + p.off_scand);
+                int* sctl = (int*)(ws + p.off_sctl);
+                const int nq_pad = ngroups * p.qgroup;
+                MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
+                MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
+                hipLaunchKernelGGL(query_bound_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)h->flags, bound);
+                for (int gi = 0; gi < ngroups; ++gi) {
+                    int nqg = nq - gi * p.qgroup < p.qgroup ? nq - gi * p.qgroup : p.qgroup;
+                    hipLaunchKernelGGL((mips_screen_kernel<NKB>), dim3(p.G), dim3(512), 3 * rb_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb,
+                                       (const char*)(qhi + gi * qgroup_bytes), (const float*)(bound + (size_t)gi * p.qgroup), nqg, gi * p.qgroup,
+                                       gmax + (size_t)gi * p.qgroup, scand, sctl, kCandCap, sctl + 1);
+                    MDR_HIP_TRY(hipGetLastError());
+                }
+                hipLaunchKernelGGL(mips_refine_kernel, dim3(h->num_cus), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
+                                   (const u64*)scand, (const int*)sctl, kCandCap, best);
+                MDR_HIP_TRY(hipGetLastError());
+                run_if = sctl + 1;  // the exact pass below runs only if the candidate list overflowed
+                h->last_kernel = "mips_screen_kernel<24>";
+            } else {
+                h->last_kernel = "mips_stream_kernel<24,0>";
+            }
+            const int Gx = (int)(n_rb < h->num_cus ? n_rb : h->num_cus);
             for (int gi = 0; gi < ngroups; ++gi) {
                 int nqg = nq - gi * p.qgroup < p.qgroup ? nq - gi * p.qgroup : p.qgroup;
-                hipLaunchKernelGGL((mips_stream_kernel<NKB, 0>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->data, (long long)h->ntotal, n_rb,
-                                   (const char*)(qfrag + (size_t)gi * p.qgroup * h->d * 4), nqg, best + (size_t)gi * p.qgroup, (u64*)nullptr,
-                                   (int*)nullptr, (u64*)nullptr, 1);
+                hipLaunchKernelGGL((mips_stream_kernel<NKB, 0>), dim3(Gx), dim3(512), 3 * rb_bytes, st, (const char*)h->hi, (const char*)h->lo,
+                                   (long long)h->ntotal, n_rb, (const char*)(qhi + gi * qgroup_bytes), (const char*)(qlo + gi * qgroup_bytes), nqg,
+                                   best + (size_t)gi * p.qgroup, (u64*)nullptr, (int*)nullptr, (u64*)nullptr, 1, run_if);
                 MDR_HIP_TRY(hipGetLastError());
             }
             hipLaunchKernelGGL(finalize_top1_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, (const u64*)best, nq, D_dev, (long long*)I_dev,
                                (long long)id_offset);
             MDR_HIP_TRY(hipGetLastError());
-            h->last_kernel = "mips_stream_kernel<24,0>";
         } else {
+            const size_t lds_bytes = 3 * rb_bytes + kStreamQ * sizeof(int);
             if (!attr_done[1]) {
-                MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_stream_kernel<NKB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)(3 * rb_bytes + kStreamQ * sizeof(int))));
+                MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_stream_kernel<NKB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 attr_done[1] = true;
             }
             for (int gi = 0; gi < ngroups; ++gi) {
                 int nqg = nq - gi * p.qgroup < p.qgroup ? nq - gi * p.qgroup : p.qgroup;
                 MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * p.qgroup * 4, st));
                 MDR_HIP_TRY(hipMemsetAsync(kth, 0, (size_t)p.G * p.qgroup * 8, st));
-                hipLaunchKernelGGL((mips_stream_kernel<NKB, 1>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->data, (long long)h->ntotal, n_rb,
-                                   (const char*)(qfrag + (size_t)gi * p.qgroup * h->d * 4), nqg, (u64*)nullptr, cand, cnt, kth, k);
+                hipLaunchKernelGGL((mips_stream_kernel<NKB, 1>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (const char*)h->lo,
+                                   (long long)h->ntotal, n_rb, (const char*)(qhi + gi * qgroup_bytes), (const char*)(qlo + gi * qgroup_bytes), nqg,
+                                   (u64*)nullptr, cand, cnt, kth, k, (const int*)nullptr);
                 MDR_HIP_TRY(hipGetLastError());
                 hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.G, p.qgroup,
                                    p.cap, k, D_dev + (size_t)gi * p.qgroup * k, (long long*)I_dev + (size_t)gi * p.qgroup * k, (long long)id_offset);
@@ -827,7 +1102,7 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
             int nqg = nq - gi * p.qgroup < p.qgroup ? nq - gi * p.qgroup : p.qgroup;
             MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * p.qgroup * 4, st));
             MDR_HIP_TRY(hipMemsetAsync(kth, 0, (size_t)p.G * p.qgroup * 8, st));
-            hipLaunchKernelGGL(mips_generic_kernel, dim3(p.G), dim3(256), 0, st, (const char*)h->data, (long long)h->ntotal, n_rb, h->nkb,
+            hipLaunchKernelGGL(mips_generic_kernel, dim3(p.G), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, (long long)h->ntotal, n_rb, h->nkb,
                                q_dev + (size_t)gi * p.qgroup * h->d, nqg, cand, cnt, kth, k);
             MDR_HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.G, p.qgroup, p.cap,

@@ -105,7 +105,7 @@ class IndexFlatIP:
         return int(_lib.lib().mdr_index_stream_bytes(self._h))
 
     def set_variant(self, v):
-        """Test hook: 0 auto, 1 generic fp32 kernel, 2 MFMA stream kernel."""
+        """Test hook: 0 auto, 1 generic fp32 kernel, 2 exact 3-MFMA stream kernel, 3 screen + refine (k == 1)."""
         _lib.check(_lib.lib().mdr_index_set_variant(self._h, int(v)))
 
     def last_kernel(self):
