@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-encoder", action="store_true", help="MIPS-only step (query embeddings synthetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only for debugging)")
+    ap.add_argument("--share-gpu", action="store_true", help="debug: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--pmc-traffic", type=float, default=None, help="HBM bytes per launch from a rocprofv3 --pmc pass")
     return ap.parse_args()
 
@@ -78,12 +80,17 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)  # "nccl" == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # "nccl" == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     from multihop_dense_retrieval_amd import index as mdr_index
     from multihop_dense_retrieval_amd import mhop

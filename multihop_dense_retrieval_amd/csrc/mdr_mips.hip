@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) row_norm2_max_kernel(const T* __restrict_
     for (int c = lane; c < d; c += 64) { float x = load_as_f32<T>(src + r * (long long)d + c); s += x * x; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0 && s == s) atomicMax(flags + 2, __float_as_int(s));
+    if (lane == 0 && s == s && __float_as_int(s) > flags[2]) atomicMax(flags + 2, __float_as_int(s));  // pre-check: one hot word
 }
 
 // one wave per query: bound[q] = c * |q| * max_row|x| + eps  (0 for padding queries)
@@ -383,11 +383,19 @@ __device__ __forceinline__ void issue_super_block(const char* __restrict__ Xhi, 
 
 __device__ __forceinline__ unsigned load_u32_l2(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int NKB>
+constexpr int kWaveCandCap = 2048;  // (query,row) candidates one wave may emit per pass before the exact fallback
+constexpr int kSampleStages = 4;    // super-blocks per workgroup the sample pass scores (x 256 workgroups x 32 rows)
+
+// MODE 0 (sample pass): score the first kSampleStages super-blocks of every workgroup, emit nothing, publish
+//         the largest s_hi per query to gmax. The kernel boundary is the grid-wide synchronisation.
+// MODE 1 (main pass):   start from gmax, score every row, append rows with s_hi >= known - 2B to this wave's
+//         PRIVATE candidate list (slot from a ballot prefix: no returning atomic, so nothing ever waits on
+//         vmcnt and the corpus DMA is never drained), tighten `known` with the wave's own maxima.
+template <int NKB, int MODE>
 __global__ void __launch_bounds__(512, 2)
 mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, const char* __restrict__ Qhi, const float* __restrict__ qbound, int nq,
-                   int q_base, unsigned* __restrict__ gmax /* [nq] ordered(max s_hi) */, u64* __restrict__ cand, int* __restrict__ cand_n,
-                   int cand_cap, int* __restrict__ overflow) {
+                   int q_base, unsigned* __restrict__ gmax /* [nq] ordered(max s_hi) */, u64* __restrict__ cand /* [waves][kWaveCandCap] */,
+                   int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SB_BYTES = 2 * NKB * kFragBytes;
     constexpr int CPW = NKB / 4;
@@ -395,12 +403,11 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = gridDim.x, b = blockIdx.x;
-    const int n_my = (n_sb - b + G - 1) / G;  // >= 1 (grid <= n_sb)
-    const int n_it = n_my + 1;                // + the revisit of super-block 0
-    auto sb_of = [&](int it) { return b + (it == n_my ? 0 : it) * G; };
+    int n_it = (n_sb - b + G - 1) / G;  // >= 1 (grid <= n_sb)
+    if (MODE == 0 && n_it > kSampleStages) n_it = kSampleStages;
 
-    issue_super_block<NKB>(Xhi, sb_of(0), lds, wave, lane);
-    issue_super_block<NKB>(Xhi, sb_of(1), lds + SB_BYTES, wave, lane);
+    issue_super_block<NKB>(Xhi, b, lds, wave, lane);
+    if (n_it > 1) issue_super_block<NKB>(Xhi, b + G, lds + SB_BYTES, wave, lane);
 
     const bool wave_active = wave * 16 < nq;
     half8 qh[NKB];
@@ -408,16 +415,26 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
         const size_t qoff = (size_t)wave * NKB * kFragBytes + lane * 16;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) qh[kb] = *(const half8*)(Qhi + qoff + kb * kFragBytes);
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(qh[kb]));  // retire the loads before the loop (see stream kernel)
     }
     const int qlocal = wave * 16 + (lane & 15);
     const bool q_valid = qlocal < nq;
-    const float band2 = q_valid ? 2.f * qbound[qlocal] : 0.f;
+    float band2 = 0.f;
+    float known = -FLT_MAX;  // largest s_hi known for this lane's query (sample pass + this wave's own rows)
+    if (MODE == 1 && q_valid) {
+        band2 = 2.f * qbound[qlocal];
+        unsigned g = gmax[qlocal];
+        if (g) known = unord32(g);
+    }
+    // retire every load above before the loop: pending VMEM results would make the compiler put vmcnt(0) in front
+    // of their first use inside the loop and drain the corpus DMA each iteration
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(qh[kb]));
+    asm volatile("" : "+v"(band2), "+v"(known));
     const unsigned sub_row = 4u * (unsigned)(lane >> 4);
-    float hmax = -FLT_MAX;       // largest s_hi this lane has seen
-    float known = -FLT_MAX;      // largest s_hi known for this query (lane, wave, or published by other workgroups)
-    float published = -FLT_MAX;  // what this wave last pushed to gmax (lanes 0..15 only)
+    float hmax = -FLT_MAX;  // largest s_hi this lane has seen
+    int my_cnt = 0;         // wave-uniform: entries in this wave's candidate list
+    u64* my_list = cand + ((size_t)b * 8 + wave) * kWaveCandCap;
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
     for (int it = 0; it < n_it; ++it) {
         if (it + 1 < n_it)
@@ -426,7 +443,21 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + 2 < n_it) issue_super_block<NKB>(Xhi, sb_of(it + 2), lds + ((it + 2) % 3) * SB_BYTES, wave, lane);
+        if (MODE == 1 && ((it + b) & 63) == 63 && wave_active) {
+            // Every 64 stages (staggered over the workgroups so gmax is not hammered by all of them at once) exchange
+            // maxima with the other workgroups. The load makes the compiler wait vmcnt(0); placed HERE, before this
+            // iteration's DMA is issued, the only VMEM ops outstanding are last iteration's (already landed) pieces.
+            float hm = fmaxf(hmax, __shfl_xor(hmax, 16));
+            hm = fmaxf(hm, __shfl_xor(hm, 32));
+            float kn = known;
+            if (lane < 16 && q_valid) {
+                if (hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
+                unsigned g = load_u32_l2(gmax + qlocal);
+                if (g) kn = fmaxf(kn, unord32(g));
+            }
+            known = __shfl(kn, lane & 15);
+        }
+        if (it + 2 < n_it) issue_super_block<NKB>(Xhi, b + (it + 2) * G, lds + ((it + 2) % 3) * SB_BYTES, wave, lane);
         if (!wave_active) continue;
 
         const char* p = lds + (it % 3) * SB_BYTES + lane * 16;
@@ -463,58 +494,58 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         const f32x4 s0 = a00 + a01, s1 = a10 + a11;
-        const unsigned row0 = (unsigned)sb_of(it) * 32u + sub_row;
+        const unsigned row0 = (unsigned)(b + it * G) * 32u + sub_row;
         const float cut = known - band2;  // a row below this cannot beat the row that produced `known`
-        const bool emit = it > 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float sc = h ? s1[r] : s0[r];
                 const unsigned row = row0 + 16u * h + r;
-                if ((long long)row < n_rows && q_valid) {
-                    if (emit && sc >= cut) {
-                        int pos = atomicAdd(cand_n, 1);
-                        if (pos < cand_cap) cand[pos] = ((u64)(unsigned)(q_base + qlocal) << 32) | row;
-                        else *overflow = 1;
+                const bool ok = (long long)row < n_rows && q_valid;
+                if (ok) hmax = fmaxf(hmax, sc);
+                if (MODE == 1) {
+                    const bool hit = ok && sc >= cut;
+                    const u64 m = __ballot(hit);
+                    if (m) {  // wave-uniform
+                        const int slot = my_cnt + __popcll(m & lt);
+                        if (hit && slot < kWaveCandCap) my_list[slot] = ((u64)(unsigned)(q_base + qlocal) << 32) | row;
+                        my_cnt += __popcll(m);
                     }
-                    hmax = fmaxf(hmax, sc);
                 }
             }
-        // share the maximum: 4 lanes per query, then (lanes 0..15) the other workgroups through gmax
+        if (MODE == 1) {  // share the maximum between the 4 lanes of a query
+            float hm = fmaxf(hmax, __shfl_xor(hmax, 16));
+            hm = fmaxf(hm, __shfl_xor(hm, 32));
+            known = fmaxf(known, hm);
+        }
+    }
+    if (MODE == 0) {
         float hm = fmaxf(hmax, __shfl_xor(hmax, 16));
         hm = fmaxf(hm, __shfl_xor(hm, 32));
-        float kn = fmaxf(known, hm);
-        // Publishing is fire-and-forget, but READING gmax is a VMEM load the compiler waits for with vmcnt(0),
-        // which also drains the in-flight corpus DMA; so refresh on a geometric schedule (it = 1,2,3,4,6,8,12,16,..):
-        // the expected number of extra candidates per query stays O(1) per interval (harmonic argument).
-        const bool refresh = it < 4 || ((it & (it - 1)) == 0) || (((it / 3) & (it / 3 - 1)) == 0 && it % 3 == 0);
-        if (refresh) {
-            if (lane < 16 && q_valid) {
-                if (hm > published) { atomicMax(gmax + qlocal, ord32(hm)); published = hm; }
-                unsigned g = load_u32_l2(gmax + qlocal);
-                if (g) kn = fmaxf(kn, unord32(g));
-            }
-            kn = __shfl(kn, lane & 15);
-        }
-        known = kn;
+        if (lane < 16 && q_valid && hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
+    } else if (lane == 0) {
+        cand_cnt[b * 8 + wave] = my_cnt < kWaveCandCap ? my_cnt : kWaveCandCap;
+        if (my_cnt > kWaveCandCap) *overflow = 1;
     }
 }
 
-// exact re-scoring of the screen kernel's candidates: one wave per (query, row), fp32 FMA on both planes
+// exact re-scoring of the screen kernel's candidates: 16 lanes per (query, row), fp32 FMA on both planes;
+// one 256-thread block per source wave list, 16 candidates in flight per block
 __global__ void __launch_bounds__(256)
 mips_refine_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, const u64* __restrict__ cand,
-                   const int* __restrict__ cand_n, int cand_cap, u64* __restrict__ best) {
-    const int lane = threadIdx.x & 63;
-    const int wpb = blockDim.x >> 6;
-    const int n = min(*cand_n, cand_cap);
+                   const int* __restrict__ cand_cnt, u64* __restrict__ best) {
+    const int n = cand_cnt[blockIdx.x];
+    if (n == 0) return;
+    const u64* list = cand + (size_t)blockIdx.x * kWaveCandCap;
+    const int sub = threadIdx.x & 15;  // lane within the 16-lane group
     const int d = nkb * 32;
-    for (int c = blockIdx.x * wpb + (threadIdx.x >> 6); c < n; c += gridDim.x * wpb) {
-        const u64 e = cand[c];
+    for (int c = threadIdx.x >> 4; c < n; c += 16) {
+        const u64 e = list[c];
         const unsigned qi = (unsigned)(e >> 32), row = (unsigned)e;
         const size_t base = ((size_t)(row >> 4) * nkb) * kFragBytes + (size_t)(row & 15) * 16;
         float acc = 0.f;
-        for (int pc = lane; pc < nkb * 4; pc += 64) {  // piece = (k-block, 8-column group)
+        for (int pc = sub; pc < nkb * 4; pc += 16) {  // piece = (k-block, 8-column group)
             const int kb = pc >> 2, g = pc & 3;
             const size_t off = base + (size_t)kb * kFragBytes + (size_t)g * 256;
             const half8 h = *(const half8*)(Xhi + off);
@@ -524,8 +555,8 @@ mips_refine_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, i
             for (int j = 0; j < 8; ++j) acc = fmaf((float)h[j] + (float)l[j] * kLoInv, qp[j], acc);
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) atomicMax(best + qi, make_key(acc, row));
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (sub == 0) atomicMax(best + qi, make_key(acc, row));
     }
 }
 
@@ -759,7 +790,6 @@ struct mdr_index {
 
 namespace {
 
-constexpr int kCandCap = 1 << 20;  // (query,row) candidates the screen kernel may emit per pass before falling back
 
 size_t plane_bytes_per_row(const mdr_index* h) { return (size_t)h->d * 2; }
 long long pad32(long long n) { return (n + 31) / 32 * 32; }
@@ -866,8 +896,8 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     p.off_bound = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
     p.off_best = take((size_t)(nq > 0 ? nq : 1) * 8);
     p.off_gmax = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
-    p.off_scand = take(p.path == PATH_SCREEN ? (size_t)kCandCap * 8 : 0);
-    p.off_sctl = take(p.path == PATH_SCREEN ? 256 : 0);  // [0] candidate count, [1] overflow flag
+    p.off_scand = take(p.path == PATH_SCREEN ? (size_t)p.G * 8 * kWaveCandCap * 8 : 0);  // one private list per wave
+    p.off_sctl = take(p.path == PATH_SCREEN ? 256 + (size_t)p.G * 8 * 4 : 0);            // [0] overflow flag, [64..] per-wave counts
     p.off_cand = take(lists ? (size_t)p.G * p.qgroup * p.cap * 8 : 0);
     p.off_cnt = take(lists ? (size_t)p.G * p.qgroup * 4 : 0);
     p.off_kth = take(lists ? (size_t)p.G * p.qgroup * 8 : 0);
@@ -1040,29 +1070,34 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
             const int* run_if = nullptr;
             if (p.path == PATH_SCREEN) {
                 if (!attr_done[2]) {
-                    MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screen_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * rb_bytes)));
+                    MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screen_kernel<NKB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * rb_bytes)));
+                    MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screen_kernel<NKB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * rb_bytes)));
                     attr_done[2] = true;
                 }
                 float* bound = (float*)(ws + p.off_bound);
                 unsigned* gmax = (unsigned*)(ws + p.off_gmax);
                 u64* scand = (u64*)(ws + p.off_scand);
                 int* sctl = (int*)(ws + p.off_sctl);
+                int* wave_cnt = sctl + 64;
                 const int nq_pad = ngroups * p.qgroup;
                 MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
                 MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
                 hipLaunchKernelGGL(query_bound_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)h->flags, bound);
                 for (int gi = 0; gi < ngroups; ++gi) {
                     int nqg = nq - gi * p.qgroup < p.qgroup ? nq - gi * p.qgroup : p.qgroup;
-                    hipLaunchKernelGGL((mips_screen_kernel<NKB>), dim3(p.G), dim3(512), 3 * rb_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb,
-                                       (const char*)(qhi + gi * qgroup_bytes), (const float*)(bound + (size_t)gi * p.qgroup), nqg, gi * p.qgroup,
-                                       gmax + (size_t)gi * p.qgroup, scand, sctl, kCandCap, sctl + 1);
+                    const char* qg = qhi + gi * qgroup_bytes;
+                    hipLaunchKernelGGL((mips_screen_kernel<NKB, 0>), dim3(p.G), dim3(512), 3 * rb_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
+                                       (const float*)(bound + (size_t)gi * p.qgroup), nqg, gi * p.qgroup, gmax + (size_t)gi * p.qgroup, scand, wave_cnt,
+                                       sctl);
+                    hipLaunchKernelGGL((mips_screen_kernel<NKB, 1>), dim3(p.G), dim3(512), 3 * rb_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
+                                       (const float*)(bound + (size_t)gi * p.qgroup), nqg, gi * p.qgroup, gmax + (size_t)gi * p.qgroup, scand, wave_cnt,
+                                       sctl);
+                    hipLaunchKernelGGL(mips_refine_kernel, dim3(p.G * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
+                                       (const u64*)scand, (const int*)wave_cnt, best);
                     MDR_HIP_TRY(hipGetLastError());
                 }
-                hipLaunchKernelGGL(mips_refine_kernel, dim3(h->num_cus), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
-                                   (const u64*)scand, (const int*)sctl, kCandCap, best);
-                MDR_HIP_TRY(hipGetLastError());
-                run_if = sctl + 1;  // the exact pass below runs only if the candidate list overflowed
-                h->last_kernel = "mips_screen_kernel<24>";
+                run_if = sctl;  // the exact pass below runs only if a candidate list overflowed
+                h->last_kernel = "mips_screen_kernel<24,1>";
             } else {
                 h->last_kernel = "mips_stream_kernel<24,0>";
             }

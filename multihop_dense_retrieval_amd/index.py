@@ -137,6 +137,21 @@ def topk_merge(D_parts, I_parts):
     return D, I
 
 
+def all_gather_dim0(t, world, group=None):
+    """all_gather_into_tensor along dim 0. RCCL ("nccl") takes device tensors directly; with the gloo backend
+    (CPU tests, or several ranks sharing one GPU while debugging) device tensors are staged through the host."""
+    import torch.distributed as dist
+    out_shape = (world * t.shape[0],) + tuple(t.shape[1:])
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()
+        out = torch.empty(out_shape, dtype=t.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(t.device)
+    out = torch.empty(out_shape, dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out
+
+
 def shard_bounds(n_total, world_size, rank):
     """Contiguous row blocks: rank r owns [r*ceil(N/W), min(N, (r+1)*ceil(N/W)))  (SURVEY.md §8e)."""
     per = -(-int(n_total) // int(world_size))
@@ -196,9 +211,7 @@ class ShardedIndexFlatIP:
         # one packed buffer -> ONE collective per hop: scores as int32 bit patterns next to the ids
         packed = torch.stack([Dt.contiguous().view(torch.int32).to(torch.int64), It.contiguous()], 0)
         # concatenated along dim 0 (the layout both gloo and RCCL accept), viewed as [world, 2, nq, k]
-        gathered = torch.empty((self.world * 2, nq, k), dtype=torch.int64, device=packed.device)
-        self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
-        gathered = gathered.view(self.world, 2, nq, k)
+        gathered = all_gather_dim0(packed, self.world, self.group).view(self.world, 2, nq, k)
         Dp = gathered[:, 0].to(torch.int32).view(torch.float32).reshape(self.world, nq, k)
         Ip = gathered[:, 1].reshape(self.world, nq, k)
         Dm, Im = self.merge_fn(Dp.contiguous(), Ip.contiguous())

@@ -179,16 +179,14 @@ class SyntheticTwoHop:
     def _encode(self, ids, mask):
         if self.world > 1:
             # data-parallel encoder: each rank encodes a contiguous slice, embeddings are all-gathered
-            import torch.distributed as dist
             n = ids.shape[0]
             per = -(-n // self.world)
             lo, hi = min(n, self.rank * per), min(n, (self.rank + 1) * per)
             part = torch.zeros((per, self.d), device=self.device)
             if hi > lo:
                 part[: hi - lo] = self.encoder.encode_q(ids[lo:hi], mask[lo:hi], None)
-            full = torch.empty((self.world * per, self.d), device=self.device)
-            dist.all_gather_into_tensor(full, part)
-            return full[:n].contiguous()
+            from .index import all_gather_dim0
+            return all_gather_dim0(part, self.world)[:n].contiguous()
         return self.encoder.encode_q(ids, mask, None)
 
     # -- one step ----------------------------------------------------------------------------------------
