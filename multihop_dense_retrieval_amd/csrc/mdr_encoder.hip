@@ -14,15 +14,16 @@
 // Kernels
 //   enc_lens / enc_scan / enc_scatter   packing: lengths, cu_seqlens, token -> (row, position id)
 //   embed_ln                            word + position + type embedding gather, LayerNorm -> fp16
-//   gemm_f16<EPI>                       C = A[M,K] x W[N,K]^T on v_mfma_f32_16x16x32_f16, 128x128x64 tiles,
+//   gemm_f16<EPI,WM,STAGES>             C = A[M,K] x W[N,K]^T on v_mfma_f32_16x16x32_f16, (64..256)x128x64 tiles,
 //                                       global_load_lds staging (XOR-swizzled via the source address),
 //                                       fused bias / bias+GELU / bias+residual epilogues
-//   attention<NT>                       per (sequence, head, 64 queries): K and V^T of the sequence in LDS,
+//   attention<NT>                       per (sequence, head): K and V^T of the sequence staged in LDS once,
 //                                       S = QK^T on MFMA, fp32 softmax in registers, O = PV on MFMA
 //   layernorm                           fp32 [T,H] -> fp16 (hidden state) or fp32 (final embedding)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -148,7 +149,7 @@ embed_ln_kernel(const long long* __restrict__ ids, const int* __restrict__ tok_s
         if (i < n) { int e = lane + 64 * i; out[(size_t)t * H + e] = (_Float16)((x[i] - mu) * rstd * g[e] + bta[e]); }
 }
 
-// fp32 rows -> LayerNorm -> fp16 (out16) and/or fp32 (out32); one wave per row
+// fp32 rows -> LayerNorm -> fp16 (out16) and/or fp32 (out32); one wave per row, 16-byte loads (H % 256 == 0 fast path)
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const float* __restrict__ in, int rows_cap, const int* __restrict__ rows_dev, int H, const float* __restrict__ g,
                  const float* __restrict__ bta, float eps, _Float16* __restrict__ out16, float* __restrict__ out32) {
@@ -157,6 +158,40 @@ layernorm_kernel(const float* __restrict__ in, int rows_cap, const int* __restri
     const int rows = rows_dev ? min(*rows_dev, rows_cap) : rows_cap;
     if (t >= rows) return;
     const float* r = in + (size_t)t * H;
+    if ((H & 255) == 0) {
+        const int n4 = H >> 8;  // float4 per lane (<= 4)
+        f32x4 x[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n4) { x[i] = *(const f32x4*)(r + (lane + 64 * i) * 4); s += x[i][0] + x[i][1] + x[i][2] + x[i][3]; }
+        const float mu = wave_sum(s) / H;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float dlt = x[i][j] - mu; v += dlt * dlt; }
+            }
+        const float rstd = rsqrtf(wave_sum(v) / H + eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n4) {
+                const int e = (lane + 64 * i) * 4;
+                const f32x4 g4 = *(const f32x4*)(g + e), b4 = *(const f32x4*)(bta + e);
+                f32x4 y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = (x[i][j] - mu) * rstd * g4[j] + b4[j];
+                if (out16) {
+                    half4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)y[j];
+                    *(half4*)(out16 + (size_t)t * H + e) = o;
+                }
+                if (out32) *(f32x4*)(out32 + (size_t)t * H + e) = y;
+            }
+        return;
+    }
     const int n = H >> 6;
     float x[kMaxPerLane];
     float s = 0.f;
@@ -193,93 +228,132 @@ __global__ void f32_to_f16_kernel(const float* __restrict__ in, _Float16* __rest
 }
 
 // ---- GEMM: C[M,N] = A[M,K] (fp16, row-major) x W[N,K]^T (fp16, row-major) -----------------------------
+// Block tile BM x BN x 64 computed by WGM x WGN waves (wave tile = (BM/WGM) x (BN/WGN) as 16x16 MFMA tiles),
+// STAGES-deep LDS ring filled by global_load_lds, one barrier per K-step, counted vmcnt so STAGES-2 stages stay
+// in flight across it. Instantiated shapes (launch_gemm picks by problem size):
+//   256x256, 4x2 waves (wave 64x128), 2 stages, 128 KiB, 1 block/CU : large M -- halves the L2->LDS bytes per flop
+//   128x128, 2x2 waves (wave 64x64),  2 stages,  64 KiB, 2 blocks/CU: medium M
+//    64x64,  2x2 waves (wave 32x32),  2 stages,  32 KiB, 4-5 blocks/CU: small M (hop 1, per-rank slices, CLS projection)
 enum { EPI_BIAS_F16 = 0, EPI_BIAS_GELU_F16 = 1, EPI_BIAS_RES_F32 = 2, EPI_BIAS_F32 = 3 };
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kGemmStage = (BM + BN) * BK * 2;  // 32 KiB per stage
-constexpr int kGemmLds = 2 * kGemmStage;
+constexpr int BK = 64;
 
-__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, branch-free): libm's erff costs ~60 divergent instructions
+// per value, which made the GELU epilogue as expensive as the MFMA loop of its tile.
+__device__ inline float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.f - poly * exp2f(-ax * ax * 1.4426950408889634f);
+    return copysignf(e, x);
+}
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
 
-template <int EPI>
-__global__ void __launch_bounds__(256)
+template <int BM_, int BN_, int WGM_, int WGN_, int STAGES_>
+struct GemmCfg {
+    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, STAGES = STAGES_;
+    static constexpr int THREADS = 64 * WGM * WGN;
+    static constexpr int MT = BM / WGM / 16, NT = BN / WGN / 16;  // 16x16 tiles per wave
+    static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
+    static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int A_CHUNKS = BM * 8 / THREADS, W_CHUNKS = BN * 8 / THREADS;  // 16-B DMA pieces per thread per stage
+    static constexpr int PER_STAGE = A_CHUNKS + W_CHUNKS;
+    static_assert(BM * 8 % THREADS == 0 && BN * 8 % THREADS == 0, "tile must split evenly over the threads");
+};
+
+template <int EPI, typename C>
+__global__ void __launch_bounds__(C::THREADS)
 gemm_f16_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M_cap,
                 const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo, const _Float16* __restrict__ res, int ldr) {
+    constexpr int STAGES = C::STAGES, MT = C::MT, NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int M = M_dev ? min(*M_dev, M_cap) : M_cap;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int ntn = N / C::BN;
+    const int bid = blockIdx.x;  // n fastest: the blocks sharing an A tile are launched together (measured best)
+    const int m0 = (bid / ntn) * C::BM, n0 = (bid % ntn) * C::BN;
     if (m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / C::WGN, wn = wave % C::WGN;
     const int g = lane >> 4, lr = lane & 15;
 
-    // DMA plan: tile = 128 rows x 8 slots of 16 B; LDS slot p = i*256 + tid holds global chunk
-    // (row = p>>3, k-slot = (p&7) ^ (row&7)): linear LDS image, XOR swizzle applied on the source side
-    const _Float16* a_src[4];
-    const _Float16* w_src[4];
+    // DMA plan: LDS slot p (16 B) of a tile holds global chunk (row = p>>3, k-slot = (p&7) ^ (row&7)): the LDS image is
+    // linear in lane order (what global_load_lds writes), the XOR swizzle lives in the SOURCE address (guide rule 21)
+    const _Float16* a_src[C::A_CHUNKS];
+    const _Float16* w_src[C::W_CHUNKS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int p = i * 256 + tid;
-        int row = p >> 3, s = (p & 7) ^ (row & 7);
+    for (int i = 0; i < C::A_CHUNKS; ++i) {
+        const int p = i * C::THREADS + tid;
+        const int row = p >> 3, s = (p & 7) ^ (row & 7);
         int ar = m0 + row;
         ar = ar < M ? ar : M - 1;  // rows past M are computed on a valid row and never stored
         a_src[i] = A + (size_t)ar * lda + s * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < C::W_CHUNKS; ++i) {
+        const int p = i * C::THREADS + tid;
+        const int row = p >> 3, s = (p & 7) ^ (row & 7);
         w_src[i] = W + (size_t)(n0 + row) * K + s * 8;
     }
     auto issue = [&](int stage, int k0) {
-        char* base = lds + stage * kGemmStage;
+        char* base = lds + stage * C::STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(MDR_GPTR(a_src[i] + k0), MDR_LPTR(base + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        for (int i = 0; i < C::A_CHUNKS; ++i)
+            __builtin_amdgcn_global_load_lds(MDR_GPTR(a_src[i] + k0), MDR_LPTR(base + (i * C::THREADS + wave * 64) * 16), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds(MDR_GPTR(w_src[i] + k0), MDR_LPTR(base + BM * BK * 2 + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        for (int i = 0; i < C::W_CHUNKS; ++i)
+            __builtin_amdgcn_global_load_lds(MDR_GPTR(w_src[i] + k0), MDR_LPTR(base + C::A_BYTES + (i * C::THREADS + wave * 64) * 16), 16, 0, 0);
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int sw0 = ((0 * 4 + g) ^ (lane & 7)) << 4, sw1 = ((1 * 4 + g) ^ (lane & 7)) << 4;
-    const int a_off = (wm * 64 + lr) * 128, w_off = BM * BK * 2 + (wn * 64 + lr) * 128;
+    const int a_off = (wm * MT * 16 + lr) * 128, w_off = C::A_BYTES + (wn * NT * 16 + lr) * 128;
 
     const int KT = K / BK;
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < KT) issue(s, s * BK);
     for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) issue(cur ^ 1, (kt + 1) * BK);
-        const char* base = lds + cur * kGemmStage;
+        // stage kt has landed; at most STAGES-2 younger stages stay in flight across the barrier
+        const int younger = min(STAGES - 2, KT - 1 - kt);
+        if (STAGES >= 4 && younger >= 2)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::PER_STAGE * 2 < 64 ? C::PER_STAGE * 2 : 63) : "memory");
+        else if (STAGES >= 3 && younger >= 1)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::PER_STAGE) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + STAGES - 1 < KT) issue((kt + STAGES - 1) % STAGES, (kt + STAGES - 1) * BK);
+        const char* base = lds + (kt % STAGES) * C::STAGE_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int sw = s ? sw1 : sw0;
-            half8 af[4], wf[4];
+            half8 af[MT], wf[NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[t] = *(const half8*)(base + a_off + t * 16 * 128 + sw);
-                wf[t] = *(const half8*)(base + w_off + t * 16 * 128 + sw);
-            }
+            for (int t = 0; t < MT; ++t) af[t] = *(const half8*)(base + a_off + t * 16 * 128 + sw);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int t = 0; t < NT; ++t) wf[t] = *(const half8*)(base + w_off + t * 16 * 128 + sw);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
     }
 
     // epilogue: lane holds C[m = .. + lr][n = .. + 4g + r], r = 0..3 (first MFMA operand = W rows)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + lr;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + (wm * MT + mt) * 16 + lr;
         if (m >= M) continue;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + 4 * g;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + (wn * NT + nt) * 16 + 4 * g;
             const f32x4 b4 = *(const f32x4*)(bias + n);
             f32x4 v = acc[mt][nt] + b4;
             if (EPI == EPI_BIAS_GELU_F16) {
@@ -303,9 +377,15 @@ gemm_f16_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
     }
 }
 
-// ---- attention: softmax(Q K^T / 8 + mask) V for one (sequence, head, 64-query tile) --------------------
+using GemmBig = GemmCfg<256, 256, 4, 2, 2>;
+using GemmMid = GemmCfg<128, 128, 2, 2, 2>;
+using GemmSmall = GemmCfg<64, 64, 2, 2, 2>;
+
+// ---- attention: softmax(Q K^T / 8 + mask) V for one (sequence, head) ------------------------------------
+// K (XOR-swizzled rows) and V^T of the whole sequence are staged in LDS ONCE, then the 8 waves walk the
+// sequence's queries 128 at a time (16 per wave).
 template <int NT>  // key tiles of 16 the sequence may have (len <= 16*NT)
-__global__ void __launch_bounds__(256) attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
+__global__ void __launch_bounds__(512) attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
                                                         _Float16* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int LP = NT * 16;
@@ -315,104 +395,118 @@ __global__ void __launch_bounds__(256) attention_kernel(const _Float16* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, lr = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int b = blockIdx.y, h = blockIdx.x;
     const int start = cu[b], len = cu[b + 1] - start;
-    if (q0 >= len) return;
+    if (len <= 0) return;
     const int nt = (len + 15) >> 4;
     const int np = (nt + 1) >> 1;
     const int H3 = 3 * H;
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    for (int p = tid; p < np * 32 * 8; p += 256) {
-        const int row = p >> 3, s = p & 7;
-        half8 kv = zero8, vv = zero8;
-        if (row < len) {
-            const _Float16* src = qkv + (size_t)(start + row) * H3 + h * 64 + s * 8;
-            kv = *(const half8*)(src + H);
-            vv = *(const half8*)(src + 2 * H);
-        }
-        *(half8*)((char*)Ks + row * 128 + ((s ^ (row & 7)) << 4)) = kv;
+    // staging: 4 (row, 16-byte chunk) items per thread per round, all 8 global loads issued before the LDS writes
+    const int items = np * 32 * 8;
+    for (int p0 = tid; p0 < items; p0 += 4 * 512) {
+        half8 kv[4], vv[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[(s * 8 + j) * VS + row] = vv[j];
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * 512, row = p >> 3, s = p & 7;
+            kv[u] = zero8;
+            vv[u] = zero8;
+            if (p < items && row < len) {
+                const _Float16* src = qkv + (size_t)(start + row) * H3 + h * 64 + s * 8;
+                kv[u] = *(const half8*)(src + H);
+                vv[u] = *(const half8*)(src + 2 * H);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * 512, row = p >> 3, s = p & 7;
+            if (p < items) {
+                *(half8*)((char*)Ks + row * 128 + ((s ^ (row & 7)) << 4)) = kv[u];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Vt[(s * 8 + j) * VS + row] = vv[u][j];
+            }
+        }
     }
     __syncthreads();
-    if (q0 + wave * 16 >= len) return;  // no barrier after this point
 
-    const int qi = q0 + wave * 16 + lr;
-    const bool qvalid = qi < len;
-    const int qrow = qvalid ? qi : len - 1;
-    half8 qf[2];
+    for (int q0 = wave * 16; q0 < len; q0 += 128) {  // no barrier inside: the 8 waves run independently from here
+        const int qi = q0 + lr;
+        const bool qvalid = qi < len;
+        const int qrow = qvalid ? qi : len - 1;
+        half8 qf[2];
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const half8*)(qkv + (size_t)(start + qrow) * H3 + h * 64 + ds * 32 + g * 8);
+        for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const half8*)(qkv + (size_t)(start + qrow) * H3 + h * 64 + ds * 32 + g * 8);
 
-    // S^T tiles: lane holds keys 16t + 4g + r (r = 0..3) for query lr
-    f32x4 s[NT];
-    float mx = -INFINITY;
+        // S^T tiles: lane holds keys 16t + 4g + r (r = 0..3) for query lr
+        f32x4 s[NT];
+        float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        if (t < nt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) {
+            s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (t < nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ds = 0; ds < 2; ++ds) {
-                const half8 kf = *(const half8*)((const char*)Ks + (t * 16 + lr) * 128 + (((ds * 4 + g) ^ (lane & 7)) << 4));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ds], acc, 0, 0, 0);
-            }
+                for (int ds = 0; ds < 2; ++ds) {
+                    const half8 kf = *(const half8*)((const char*)Ks + (t * 16 + lr) * 128 + (((ds * 4 + g) ^ (lane & 7)) << 4));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ds], acc, 0, 0, 0);
+                }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = t * 16 + 4 * g + r;
-                s[t][r] = key < len ? acc[r] * 0.125f : -INFINITY;
-                mx = fmaxf(mx, s[t][r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * 16 + 4 * g + r;
+                    s[t][r] = key < len ? acc[r] * 0.125f : -INFINITY;
+                    mx = fmaxf(mx, s[t][r]);
+                }
             }
         }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-        if (t < nt) {
+        for (int t = 0; t < NT; ++t)
+            if (t < nt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = exp2f((s[t][r] - mx) * 1.4426950408889634f);
-                s[t][r] = e;
-                sum += e;
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f((s[t][r] - mx) * 1.4426950408889634f);
+                    s[t][r] = e;
+                    sum += e;
+                }
             }
-        }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.f / sum;
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.f / sum;
 
-    // O^T = V^T P^T. k-slot (g, j) of both operands <-> key 32pt + (j < 4 ? 4g + j : 16 + 4g + j - 4):
-    // the P operand is then exactly this lane's own S^T registers, no cross-lane traffic.
-    f32x4 o[4];
+        // O^T = V^T P^T. k-slot (g, j) of both operands <-> key 32pt + (j < 4 ? 4g + j : 16 + 4g + j - 4):
+        // the P operand is then exactly this lane's own S^T registers, no cross-lane traffic.
+        f32x4 o[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int pt = 0; pt < NT / 2; ++pt)
-        if (pt < np) {
-            half8 pf;
+        for (int pt = 0; pt < NT / 2; ++pt)
+            if (pt < np) {
+                half8 pf;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pf[j] = (_Float16)(s[2 * pt][j] * inv);
-                pf[4 + j] = (2 * pt + 1 < nt) ? (_Float16)(s[2 * pt + 1][j] * inv) : (_Float16)0.f;
+                for (int j = 0; j < 4; ++j) {
+                    pf[j] = (_Float16)(s[2 * pt][j] * inv);
+                    pf[4 + j] = (2 * pt + 1 < nt) ? (_Float16)(s[2 * pt + 1][j] * inv) : (_Float16)0.f;
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const _Float16* vp = Vt + (dt * 16 + lr) * VS + pt * 32 + 4 * g;
+                    const half4 lo = *(const half4*)vp;
+                    const half4 hi = *(const half4*)(vp + 16);
+                    const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+                }
             }
+        if (qvalid) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const _Float16* vp = Vt + (dt * 16 + lr) * VS + pt * 32 + 4 * g;
-                const half4 lo = *(const half4*)vp;
-                const half4 hi = *(const half4*)(vp + 16);
-                const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+                half4 w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = (_Float16)o[dt][r];
+                *(half4*)(ctx + (size_t)(start + qi) * H + h * 64 + dt * 16 + 4 * g) = w;
             }
-        }
-    if (qvalid) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            half4 w;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) w[r] = (_Float16)o[dt][r];
-            *(half4*)(ctx + (size_t)(start + qi) * H + h * 64 + dt * 16 + 4 * g) = w;
         }
     }
 }
@@ -431,6 +525,7 @@ using namespace mdr;
 struct mdr_encoder {
     mdr_encoder_config cfg{};
     int device = 0;
+    int num_cus = 256;
     std::vector<void*> allocs;
     float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
     struct Layer {
@@ -472,18 +567,32 @@ Workspace carve(const mdr_encoder_config& c, int B, int L, char* base) {
     return w;
 }
 
-template <int EPI>
-int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
-                const _Float16* res, int ldr, hipStream_t st) {
+template <int EPI, typename C>
+int launch_gemm_cfg(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
+                    const _Float16* res, int ldr, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_f16_kernel<EPI, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr = true;
     }
-    dim3 grid(N / BN, (M_cap + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_f16_kernel<EPI>), grid, dim3(256), kGemmLds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr);
+    const int blocks = (N / C::BN) * ((M_cap + C::BM - 1) / C::BM);
+    hipLaunchKernelGGL((gemm_f16_kernel<EPI, C>), dim3(blocks), dim3(C::THREADS), C::LDS_BYTES, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
+}
+
+// M_est: expected number of valid rows (the packed token count is only known on the device)
+template <int EPI>
+int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
+                const _Float16* res, int ldr, int M_est, int num_cus, hipStream_t st) {
+    static int sel = getenv("MDR_GEMM_CFG") ? atoi(getenv("MDR_GEMM_CFG")) : 0;  // experiment knob: 1 small, 2 mid, 3 big
+    const long long big_blocks = (N % 256 == 0) ? (long long)(N / 256) * ((M_est + 255) / 256) : 0;
+    const long long mid_blocks = (long long)(N / 128) * ((M_est + 127) / 128);
+    if (sel == 3 ? big_blocks > 0 : (sel == 0 && big_blocks >= (long long)num_cus * 3 / 4))
+        return launch_gemm_cfg<EPI, GemmBig>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
+    if (sel == 2 || (sel == 0 && mid_blocks >= (long long)num_cus * 2))
+        return launch_gemm_cfg<EPI, GemmMid>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
+    return launch_gemm_cfg<EPI, GemmSmall>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
 }
 
 template <int NT>
@@ -494,8 +603,8 @@ int launch_attention(const _Float16* qkv, const int* cu, int B, int L, int H, in
         MDR_HIP_TRY(hipFuncSetAttribute((const void*)attention_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    dim3 grid((L + 63) / 64, heads, B);
-    hipLaunchKernelGGL((attention_kernel<NT>), grid, dim3(256), lds, st, qkv, cu, H, ctx);
+    dim3 grid(heads, B);
+    hipLaunchKernelGGL((attention_kernel<NT>), grid, dim3(512), lds, st, qkv, cu, H, ctx);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }
@@ -526,6 +635,10 @@ int mdr_encoder_create(const mdr_encoder_config* cfg, const mdr_tensor* tensors,
     MDR_REQUIRE(h != nullptr, "out of host memory");
     h->cfg = *cfg;
     h->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
+    }
     const int H = cfg->hidden, F = cfg->ffn;
 
     float* staging = nullptr;
@@ -643,6 +756,8 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
     Workspace w = carve(c, batch, seq_len, base);
     const int B = batch, L = seq_len, H = c.hidden, F = c.ffn;
     const int Tcap = B * L;
+    const int Test = Tcap - Tcap / 3;  // tile-shape heuristic only: packed token count expected on the device
+    const int ncu = h->num_cus;
     const long long* ids = (const long long*)ids_dev;
     const long long* mask = (const long long*)mask_dev;
 
@@ -656,26 +771,26 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
     int rc;
     for (int i = 0; i < c.layers; ++i) {
         const mdr_encoder::Layer& Ly = h->layers[i];
-        rc = launch_gemm<EPI_BIAS_F16>(w.h16, H, Ly.wqkv, Ly.bqkv, Tcap, w.total, 3 * H, H, w.qkv, 3 * H, nullptr, 0, st);
+        rc = launch_gemm<EPI_BIAS_F16>(w.h16, H, Ly.wqkv, Ly.bqkv, Tcap, w.total, 3 * H, H, w.qkv, 3 * H, nullptr, 0, Test, ncu, st);
         if (rc) return rc;
         if (L <= 128) rc = launch_attention<8>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         else if (L <= 384) rc = launch_attention<24>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         else rc = launch_attention<32>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         if (rc) return rc;
-        rc = launch_gemm<EPI_BIAS_RES_F32>(w.ctx, H, Ly.wo, Ly.bo, Tcap, w.total, H, H, w.pre, H, w.h16, H, st);
+        rc = launch_gemm<EPI_BIAS_RES_F32>(w.ctx, H, Ly.wo, Ly.bo, Tcap, w.total, H, H, w.pre, H, w.h16, H, Test, ncu, st);
         if (rc) return rc;
         hipLaunchKernelGGL(layernorm_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, (const float*)w.pre, Tcap, (const int*)w.total, H,
                            (const float*)Ly.ln1_g, (const float*)Ly.ln1_b, c.ln_eps, w.h16, (float*)nullptr);
-        rc = launch_gemm<EPI_BIAS_GELU_F16>(w.h16, H, Ly.w1, Ly.b1, Tcap, w.total, F, H, w.ffn, F, nullptr, 0, st);
+        rc = launch_gemm<EPI_BIAS_GELU_F16>(w.h16, H, Ly.w1, Ly.b1, Tcap, w.total, F, H, w.ffn, F, nullptr, 0, Test, ncu, st);
         if (rc) return rc;
-        rc = launch_gemm<EPI_BIAS_RES_F32>(w.ffn, F, Ly.w2, Ly.b2, Tcap, w.total, H, F, w.pre, H, w.h16, H, st);
+        rc = launch_gemm<EPI_BIAS_RES_F32>(w.ffn, F, Ly.w2, Ly.b2, Tcap, w.total, H, F, w.pre, H, w.h16, H, Test, ncu, st);
         if (rc) return rc;
         hipLaunchKernelGGL(layernorm_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, (const float*)w.pre, Tcap, (const int*)w.total, H,
                            (const float*)Ly.ln2_g, (const float*)Ly.ln2_b, c.ln_eps, w.h16, (float*)nullptr);
         MDR_HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(gather_cls_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, (const _Float16*)w.h16, (const int*)w.cu, B, H, w.cls16);
-    rc = launch_gemm<EPI_BIAS_F32>(w.cls16, H, h->wproj, h->bproj, B, nullptr, H, H, w.clspre, H, nullptr, 0, st);
+    rc = launch_gemm<EPI_BIAS_F32>(w.cls16, H, h->wproj, h->bproj, B, nullptr, H, H, w.clspre, H, nullptr, 0, B, ncu, st);
     if (rc) return rc;
     hipLaunchKernelGGL(layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, B, (const int*)nullptr, H, (const float*)h->lnp_g,
                        (const float*)h->lnp_b, c.ln_eps, (_Float16*)nullptr, out_dev);

@@ -79,6 +79,8 @@ class _HipRobertaEncoder:
         self._shapes = expected_state_dict_shapes(config)
         self._h = ctypes.c_void_p()
         self._ws = None
+        self._graphs = {}
+        self.use_graphs = True
         self.device = None
         self.training = False
 
@@ -128,18 +130,53 @@ class _HipRobertaEncoder:
         if ids.dim() != 2 or ids.shape != msk.shape:
             raise ValueError(f"input_ids {tuple(ids.shape)} and mask {tuple(msk.shape)} must both be [B, L]")
         B, L = ids.shape
+        if self.use_graphs and 0 < B * L <= self.MAX_TOKENS_PER_CALL and L <= 512:
+            return self._encode_graphed(ids, msk)
         out = torch.empty((B, self.config.hidden_size), dtype=torch.float32, device=self.device)
+        self._forward_into(ids, msk, out)
+        return out
+
+    def _forward_into(self, ids, msk, out):
+        B, L = ids.shape
         per = max(1, self.MAX_TOKENS_PER_CALL // L)
         L_ = _lib.lib()
         for lo in range(0, B, per):
             hi = min(B, lo + per)
             need = int(L_.mdr_encoder_workspace_bytes(self._h, hi - lo, L))
             if self._ws is None or self._ws.numel() < need:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("encoder workspace must be sized before graph capture")
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             _lib.check(L_.mdr_encoder_forward(self._h, ctypes.c_void_p(ids[lo:hi].data_ptr()), ctypes.c_void_p(msk[lo:hi].data_ptr()), hi - lo, L,
                                               ctypes.c_void_p(out[lo:hi].data_ptr()), ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(),
                                               _lib.current_stream_ptr(self.device)))
-        return out
+
+    def _encode_graphed(self, ids, msk):
+        """One forward is ~140 short kernel launches; for the small batches of the retrieval loop (and for each
+        rank's slice under multi-GPU data parallelism) the launch gaps dominate. The launch sequence depends only
+        on (B, L), so it is captured once per shape into a hipGraph and replayed (static input/output buffers)."""
+        key = tuple(ids.shape)
+        ent = self._graphs.get(key)
+        if ent is None:
+            sid, smk = ids.clone(), msk.clone()
+            sout = torch.empty((key[0], self.config.hidden_size), dtype=torch.float32, device=self.device)
+            self._forward_into(sid, smk, sout)  # warm-up: sizes the workspace, sets kernel attributes
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._forward_into(sid, smk, sout)
+            ent = (graph, sid, smk, sout, self._ws)
+            if len(self._graphs) >= 16:  # bounded cache (ragged last batches, corpus encoding with many widths)
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = ent
+        graph, sid, smk, sout, ws = ent
+        if ws is not self._ws:  # the workspace was re-allocated (a larger shape came by): the capture is stale
+            del self._graphs[key]
+            return self._encode_graphed(ids, msk)
+        sid.copy_(ids)
+        smk.copy_(msk)
+        graph.replay()
+        return sout.clone()
 
     # -- internals ----------------------------------------------------------------------------------------------
     def _create(self):
