@@ -151,8 +151,9 @@ embed_ln_kernel(const long long* __restrict__ ids, const int* __restrict__ tok_s
 
 // fp32 rows -> LayerNorm -> fp16 (out16) and/or fp32 (out32); one wave per row, 16-byte loads (H % 256 == 0 fast path)
 __global__ void __launch_bounds__(256)
-layernorm_kernel(const float* __restrict__ in, int rows_cap, const int* __restrict__ rows_dev, int H, const float* __restrict__ g,
-                 const float* __restrict__ bta, float eps, _Float16* __restrict__ out16, float* __restrict__ out32) {
+layernorm_kernel(const float* __restrict__ in, const _Float16* __restrict__ res, int rows_cap, const int* __restrict__ rows_dev, int H,
+                 const float* __restrict__ g, const float* __restrict__ bta, float eps, _Float16* __restrict__ out16, float* __restrict__ out32) {
+    // `res` (optional): fp16 residual added before normalising (when the producing GEMM left it out)
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rows = rows_dev ? min(*rows_dev, rows_cap) : rows_cap;
@@ -164,7 +165,15 @@ layernorm_kernel(const float* __restrict__ in, int rows_cap, const int* __restri
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i < n4) { x[i] = *(const f32x4*)(r + (lane + 64 * i) * 4); s += x[i][0] + x[i][1] + x[i][2] + x[i][3]; }
+            if (i < n4) {
+                x[i] = *(const f32x4*)(r + (lane + 64 * i) * 4);
+                if (res) {
+                    const half4 r4 = *(const half4*)(res + (size_t)t * H + (lane + 64 * i) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[i][j] += (float)r4[j];
+                }
+                s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
+            }
         const float mu = wave_sum(s) / H;
         float v = 0.f;
 #pragma unroll
@@ -197,7 +206,7 @@ layernorm_kernel(const float* __restrict__ in, int rows_cap, const int* __restri
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxPerLane; ++i)
-        if (i < n) { x[i] = r[lane + 64 * i]; s += x[i]; }
+        if (i < n) { x[i] = r[lane + 64 * i] + (res ? (float)res[(size_t)t * H + lane + 64 * i] : 0.f); s += x[i]; }
     const float mu = wave_sum(s) / H;
     float v = 0.f;
 #pragma unroll
@@ -375,6 +384,181 @@ gemm_f16_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
             }
         }
     }
+}
+
+// ---- persistent GEMM for large M ------------------------------------------------------------------------
+// K is short here (768 or 3072): a one-tile-per-block kernel spends as long filling and draining its LDS ring
+// as computing. This kernel keeps ONE 512-thread block per CU alive and walks (tile, k-step) as one flat stream:
+// the loads of the next tile's first stages are issued during the current tile's last K-steps, so the
+// global_load_lds pipeline never empties; the epilogue (bias from LDS, no register-destination VMEM load that
+// would make the compiler wait on the in-flight DMA) runs under the next tile's loads.
+// Tile 256x128x64, 8 waves as 4x2 (wave 64x64), 3-slot ring (2 stages in flight), bias vector staged in LDS once.
+// The residual of EPI_BIAS_RES_F32 is NOT added here: the LayerNorm kernel that follows adds it (res argument).
+using GemmP = GemmCfg<256, 128, 4, 2, 3>;
+static_assert(GemmP::MT == 4 && GemmP::NT == 4 && GemmP::A_CHUNKS == 4 && GemmP::W_CHUNKS <= 4, "the pinned K-step below is written for this shape");
+constexpr int kPersistBiasMax = 3072;  // floats of bias kept in LDS behind the ring (12 KiB)
+
+template <int EPI>
+__global__ void __launch_bounds__(GemmP::THREADS)
+gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M_cap,
+                    const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo, int gn) {
+    using C = GemmP;
+    constexpr int MT = C::MT, NT = C::NT;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* lds_bias = (float*)(lds + C::LDS_BYTES);
+    const int M = M_dev ? min(*M_dev, M_cap) : M_cap;
+    // XCD-aware tile assignment. Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only) and each
+    // XCD has a private 4 MiB L2. The 8 XCDs form a gm x gn grid over (m-tiles, n-tiles): XCD (xm, xn) owns m-tiles
+    // xm, xm+gm, .. and n-tiles xn, xn+gn, .., walked m-major by its G/8 workgroups, so the blocks sharing an A tile run
+    // on ONE L2 at the same time and each L2 only ever holds 1/gn of W. Without it every XCD pulled all of A through the
+    // fabric (measured: 8x the algorithmic A traffic, the FFN2 GEMM ran at the fabric's 5.8 TB/s).
+    const int ntn = N / C::BN, ntm = (M + C::BM - 1) / C::BM;
+    const int gm = 8 / gn;
+    const int xcd = blockIdx.x & 7, xm = xcd / gn, xn = xcd % gn;
+    const int cm = xm < ntm ? (ntm - xm + gm - 1) / gm : 0, cn = xn < ntn ? (ntn - xn + gn - 1) / gn : 0;
+    const int lb = blockIdx.x >> 3, G = gridDim.x >> 3;  // this XCD's workgroups
+    const int local_tiles = cm * cn;
+    if (lb >= local_tiles) return;
+    const int n_my = (local_tiles - lb + G - 1) / G;
+    auto tile_origin = [&](int j, int& m0, int& n0) {
+        const int l = lb + j * G;
+        m0 = (xm + (l / cn) * gm) * C::BM;
+        n0 = (xn + (l % cn) * gn) * C::BN;
+    };
+    const int KT = K / BK;
+    const int total_steps = n_my * KT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C::WGN, wn = wave % C::WGN;
+    const int g = lane >> 4, lr = lane & 15;
+
+    for (int i = tid; i < N; i += C::THREADS) lds_bias[i] = bias[i];  // retired by the first barrier wait below
+
+    // ---- loader state: (tile, k-step) the next DMA batch belongs to ----
+    const _Float16* a_src[C::A_CHUNKS];
+    const _Float16* w_src[C::W_CHUNKS];
+    int ld_tile = 0, ld_kt = 0, ld_step = 0;
+    auto set_load_tile = [&](int j) {
+        int m0, n0;
+        tile_origin(j, m0, n0);
+#pragma unroll
+        for (int i = 0; i < C::A_CHUNKS; ++i) {
+            const int p = i * C::THREADS + tid;
+            const int row = p >> 3, s = (p & 7) ^ (row & 7);
+            int ar = m0 + row;
+            ar = ar < M ? ar : M - 1;
+            a_src[i] = A + (size_t)ar * lda + s * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < C::W_CHUNKS; ++i) {
+            const int p = i * C::THREADS + tid;
+            const int row = p >> 3, s = (p & 7) ^ (row & 7);
+            w_src[i] = W + (size_t)(n0 + row) * K + s * 8;
+        }
+    };
+    // advance the loader to its next batch (branchy part, kept OUT of the pinned MFMA block below). Past the end of
+    // the stream the pointers simply stay on the last tile: the surplus batches land in free slots and are never read,
+    // which keeps the DMA count per K-step constant (vmcnt(PER_STAGE) is then exact at every step).
+    auto advance_loader = [&]() {
+        if (ld_step < total_steps && ld_kt == 0) set_load_tile(ld_tile);
+    };
+    auto loader_done = [&]() {
+        ++ld_step;
+        if (ld_step < total_steps && ++ld_kt == KT) { ld_kt = 0; ++ld_tile; }
+    };
+
+    const int sw0 = ((0 * 4 + g) ^ (lane & 7)) << 4, sw1 = ((1 * 4 + g) ^ (lane & 7)) << 4;
+    const int a_off = (wm * MT * 16 + lr) * 128, w_off = C::A_BYTES + (wn * NT * 16 + lr) * 128;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bias loads above, before any DMA is in flight
+#pragma unroll
+    for (int pre = 0; pre < 2; ++pre) {
+        advance_loader();
+        char* base = lds + (ld_step % 3) * C::STAGE_BYTES;
+        const int k0 = ld_kt * BK;
+#pragma unroll
+        for (int i = 0; i < C::A_CHUNKS; ++i)
+            __builtin_amdgcn_global_load_lds(MDR_GPTR(a_src[i] + k0), MDR_LPTR(base + (i * C::THREADS + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < C::W_CHUNKS; ++i)
+            __builtin_amdgcn_global_load_lds(MDR_GPTR(w_src[i] + k0), MDR_LPTR(base + C::A_BYTES + (i * C::THREADS + wave * 64) * 16), 16, 0, 0);
+        loader_done();
+    }
+    int step = 0;
+    for (int j = 0; j < n_my; ++j) {
+        int m0, n0;
+        tile_origin(j, m0, n0);
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < KT; ++kt, ++step) {
+            // batch `step` has landed; exactly one younger batch stays in flight across the barrier. Epilogue stores
+            // issued since only make this wait more conservative (vmcnt completes in order).
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::PER_STAGE) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            advance_loader();
+            // ---- one straight-line block: LDS fragment reads, 32 MFMAs, and the 6 DMA pieces of batch step+2 (into the
+            // slot read at step-1, free since the barrier) spread BETWEEN the MFMAs. Issued in a burst right after the
+            // barrier they cost each wave ~1k cycles of VMEM issue stall while both waves of a SIMD sit idle.
+            const char* base = lds + (step % 3) * C::STAGE_BYTES;
+            char* lbase = lds + (ld_step % 3) * C::STAGE_BYTES;
+            const int k0 = ld_kt * BK;
+            half8 af0[MT], wf0[NT], af1[MT], wf1[NT];
+#pragma unroll
+            for (int q = 0; q < MT; ++q) af0[q] = *(const half8*)(base + a_off + q * 16 * 128 + sw0);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) wf0[q] = *(const half8*)(base + w_off + q * 16 * 128 + sw0);
+            __builtin_amdgcn_sched_barrier(0);
+            // {4 MFMA (k-sub 0), 2 fragment reads for k-sub 1, 1 DMA piece} x 4, order pinned with hard scheduling barriers
+            // (sched_group_barrier does not move global_load_lds: it stays a burst)
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[grp][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[nt], af0[grp], acc[grp][nt], 0, 0, 0);
+                af1[grp] = *(const half8*)(base + a_off + grp * 16 * 128 + sw1);
+                wf1[grp] = *(const half8*)(base + w_off + grp * 16 * 128 + sw1);
+                __builtin_amdgcn_global_load_lds(MDR_GPTR(a_src[grp] + k0), MDR_LPTR(lbase + (grp * C::THREADS + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[grp][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[nt], af1[grp], acc[grp][nt], 0, 0, 0);
+                if (grp < C::W_CHUNKS)
+                    __builtin_amdgcn_global_load_lds(MDR_GPTR(w_src[grp] + k0), MDR_LPTR(lbase + C::A_BYTES + (grp * C::THREADS + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            loader_done();
+        }
+        // epilogue under the next tile's loads: lane holds C[m = .. + lr][n = .. + 4g + r]
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + (wm * MT + mt) * 16 + lr;
+            if (m >= M) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + (wn * NT + nt) * 16 + 4 * g;
+                const f32x4 b4 = *(const f32x4*)(lds_bias + n);
+                f32x4 v = acc[mt][nt] + b4;
+                if (EPI == EPI_BIAS_GELU_F16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                }
+                if (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
+                    half4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
+                    *(half4*)((_Float16*)out + (size_t)m * ldo + n) = o;
+                } else {
+                    *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus batches must have landed before the LDS is released
 }
 
 using GemmBig = GemmCfg<256, 256, 4, 2, 2>;
@@ -581,15 +765,42 @@ int launch_gemm_cfg(const _Float16* A, int lda, const _Float16* W, const float* 
     return MDR_OK;
 }
 
-// M_est: expected number of valid rows (the packed token count is only known on the device)
+template <int EPI>
+int launch_gemm_persist(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
+                        int num_cus, hipStream_t st) {
+    constexpr int lds = GemmP::LDS_BYTES + kPersistBiasMax * 4;
+    static bool attr = false;
+    if (!attr) {
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    // XCD grid: split n over gn XCDs until the W slice an L2 must keep (N*K*2/gn bytes) is <= 2.5 MiB; gn must divide 8
+    static int force_gn = getenv("MDR_GEMM_GN") ? atoi(getenv("MDR_GEMM_GN")) : 0;
+    int gn = 1;
+    while (gn < 8 && ((size_t)N * K * 2 / gn > (size_t)(5 << 19) || (N / GemmP::BN) % (gn) != 0)) gn *= 2;
+    if (force_gn == 1 || force_gn == 2 || force_gn == 4 || force_gn == 8) gn = force_gn;
+    const int grid = num_cus / 8 * 8;
+    hipLaunchKernelGGL((gemm_persist_kernel<EPI>), dim3(grid), dim3(GemmP::THREADS), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, gn);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
+// M_est: expected number of valid rows (the packed token count is only known on the device).
+// *res_added tells the caller whether the residual went into the output (else the following LayerNorm adds it).
 template <int EPI>
 int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
-                const _Float16* res, int ldr, int M_est, int num_cus, hipStream_t st) {
-    static int sel = getenv("MDR_GEMM_CFG") ? atoi(getenv("MDR_GEMM_CFG")) : 0;  // experiment knob: 1 small, 2 mid, 3 big
+                const _Float16* res, int ldr, int M_est, int num_cus, hipStream_t st, bool* res_added = nullptr) {
+    static int sel = getenv("MDR_GEMM_CFG") ? atoi(getenv("MDR_GEMM_CFG")) : 0;  // experiment knob: 1 small, 2 mid, 3 big, 4 persistent
+    if (res_added) *res_added = true;
+    const long long p_tiles = (long long)(N / 128) * ((M_est + 255) / 256);
+    if ((sel == 4 || (sel == 0 && p_tiles >= (long long)num_cus * 3 / 2)) && N % 128 == 0 && N <= kPersistBiasMax) {
+        if (res_added) *res_added = false;
+        constexpr int E = EPI == EPI_BIAS_RES_F32 ? EPI_BIAS_F32 : EPI;
+        return launch_gemm_persist<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, num_cus, st);
+    }
     const long long big_blocks = (N % 256 == 0) ? (long long)(N / 256) * ((M_est + 255) / 256) : 0;
     const long long mid_blocks = (long long)(N / 128) * ((M_est + 127) / 128);
-    if (sel == 3 ? big_blocks > 0 : (sel == 0 && big_blocks >= (long long)num_cus * 3 / 4))
-        return launch_gemm_cfg<EPI, GemmBig>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
+    if (sel == 3 && big_blocks > 0) return launch_gemm_cfg<EPI, GemmBig>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
     if (sel == 2 || (sel == 0 && mid_blocks >= (long long)num_cus * 2))
         return launch_gemm_cfg<EPI, GemmMid>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
     return launch_gemm_cfg<EPI, GemmSmall>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
@@ -777,22 +988,23 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
         else if (L <= 384) rc = launch_attention<24>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         else rc = launch_attention<32>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         if (rc) return rc;
-        rc = launch_gemm<EPI_BIAS_RES_F32>(w.ctx, H, Ly.wo, Ly.bo, Tcap, w.total, H, H, w.pre, H, w.h16, H, Test, ncu, st);
+        bool res_in = true;
+        rc = launch_gemm<EPI_BIAS_RES_F32>(w.ctx, H, Ly.wo, Ly.bo, Tcap, w.total, H, H, w.pre, H, w.h16, H, Test, ncu, st, &res_in);
         if (rc) return rc;
-        hipLaunchKernelGGL(layernorm_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, (const float*)w.pre, Tcap, (const int*)w.total, H,
-                           (const float*)Ly.ln1_g, (const float*)Ly.ln1_b, c.ln_eps, w.h16, (float*)nullptr);
+        hipLaunchKernelGGL(layernorm_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, (const float*)w.pre, (const _Float16*)(res_in ? nullptr : w.h16), Tcap,
+                           (const int*)w.total, H, (const float*)Ly.ln1_g, (const float*)Ly.ln1_b, c.ln_eps, w.h16, (float*)nullptr);
         rc = launch_gemm<EPI_BIAS_GELU_F16>(w.h16, H, Ly.w1, Ly.b1, Tcap, w.total, F, H, w.ffn, F, nullptr, 0, Test, ncu, st);
         if (rc) return rc;
-        rc = launch_gemm<EPI_BIAS_RES_F32>(w.ffn, F, Ly.w2, Ly.b2, Tcap, w.total, H, F, w.pre, H, w.h16, H, Test, ncu, st);
+        rc = launch_gemm<EPI_BIAS_RES_F32>(w.ffn, F, Ly.w2, Ly.b2, Tcap, w.total, H, F, w.pre, H, w.h16, H, Test, ncu, st, &res_in);
         if (rc) return rc;
-        hipLaunchKernelGGL(layernorm_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, (const float*)w.pre, Tcap, (const int*)w.total, H,
-                           (const float*)Ly.ln2_g, (const float*)Ly.ln2_b, c.ln_eps, w.h16, (float*)nullptr);
+        hipLaunchKernelGGL(layernorm_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, (const float*)w.pre, (const _Float16*)(res_in ? nullptr : w.h16), Tcap,
+                           (const int*)w.total, H, (const float*)Ly.ln2_g, (const float*)Ly.ln2_b, c.ln_eps, w.h16, (float*)nullptr);
         MDR_HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(gather_cls_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, (const _Float16*)w.h16, (const int*)w.cu, B, H, w.cls16);
     rc = launch_gemm<EPI_BIAS_F32>(w.cls16, H, h->wproj, h->bproj, B, nullptr, H, H, w.clspre, H, nullptr, 0, B, ncu, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, B, (const int*)nullptr, H, (const float*)h->lnp_g,
+    hipLaunchKernelGGL(layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, (const _Float16*)nullptr, B, (const int*)nullptr, H, (const float*)h->lnp_g,
                        (const float*)h->lnp_b, c.ln_eps, (_Float16*)nullptr, out_dev);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
