@@ -138,6 +138,21 @@ size_t mdr_encoder_workspace_bytes(const mdr_encoder* h, int batch, int seq_len)
 int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* mask_dev, int batch, int seq_len,
                         float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Device-side construction of the hop-2 encoder inputs ==
+ *   doc = id2doc[str(doc_id)]["text"]; empty -> title and D[b][j] = -inf     /root/reference/scripts/eval/eval_mhop_retrieval.py:158-166
+ *   tokenizer.batch_encode_plus(pairs, max_length=max_q_sp_len, pad_to_max_length=True)                            :168
+ * from a corpus tokenised once ("token arena"): arena_tokens i32 [sum len], arena_offsets i64 [n_docs+1], arena_empty u8
+ * [n_docs] (1 = the passage text was empty, its arena entry is the title; may be NULL). Row b*beam+j of the output is
+ *   <s> Q_b </s></s> D_{doc_ids[b*beam+j]} </s> <pad>...   with HF `longest_first` truncation to out_len,
+ * Q_b = q_ids[b, 1 : len_b-1] (the hop-1 row without its <s> / </s>). hop1_scores (f32 [batch*beam], may be NULL) gets
+ * -inf where arena_empty is set. Everything stays on the device: no sync, no host tokenizer between the hops.
+ * ---------------------------------------------------------------------------------------------- */
+int mdr_assemble_hop2(const int64_t* q_ids_dev, const int64_t* q_mask_dev, int batch, int q_len, const int64_t* doc_ids_dev, int beam,
+                      const int32_t* arena_tokens_dev, const int64_t* arena_offsets_dev, const uint8_t* arena_empty_dev, int64_t n_docs,
+                      float* hop1_scores_dev, int out_len, int bos_id, int eos_id, int pad_id, int64_t* out_ids_dev, int64_t* out_mask_dev,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

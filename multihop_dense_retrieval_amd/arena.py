@@ -1,0 +1,85 @@
+"""Token arena: the corpus tokenised ONCE so that the hop-2 encoder inputs `<s> q </s></s> passage </s>` are
+assembled on the device from the hop-1 ids (libmdrhip.so: mdr_assemble_hop2) instead of going
+GPU -> host dict lookup -> Python tokenizer -> GPU between the hops as the reference does
+(/root/reference/scripts/eval/eval_mhop_retrieval.py:158-169). Same result: RoBERTa pair encoding, HF
+`longest_first` truncation to max_q_sp_len, empty passages replaced by their title with the hop-1 score set to -inf."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class TokenArena:
+    def __init__(self, tokens, offsets, empty=None, bos_id=0, eos_id=2, pad_id=1):
+        self.tokens = tokens.to(dtype=torch.int32).contiguous()
+        self.offsets = offsets.to(dtype=torch.int64).contiguous()
+        self.empty = None if empty is None else empty.to(dtype=torch.uint8).contiguous()
+        self.bos_id, self.eos_id, self.pad_id = bos_id, eos_id, pad_id
+        self.n_docs = int(self.offsets.numel()) - 1
+
+    def to(self, device):
+        return TokenArena(self.tokens.to(device), self.offsets.to(device), None if self.empty is None else self.empty.to(device),
+                          self.bos_id, self.eos_id, self.pad_id)
+
+    # -- builders ----------------------------------------------------------------------------------------
+    @classmethod
+    def from_corpus(cls, id2doc, tokenizer, roberta=True, max_tokens=None):
+        """id2doc: {"<row id>": {"title","text"}} (mhop.load_corpus_dict). Passages are tokenised WITHOUT special tokens;
+        an empty text falls back to the title and is flagged (eval_mhop_retrieval.py:162-165)."""
+        n = len(id2doc)
+        toks, offs, empty = [], np.zeros(n + 1, np.int64), np.zeros(n, np.uint8)
+        for i in range(n):
+            doc = id2doc[str(i)]
+            text = doc["text"]
+            if roberta and text.strip() == "":
+                text = doc["title"]
+                empty[i] = 1
+            ids = tokenizer(text, add_special_tokens=False)["input_ids"]
+            if max_tokens is not None:
+                ids = ids[:max_tokens]  # never more than max_q_sp_len - 4 tokens can survive truncation
+            toks.append(np.asarray(ids, np.int32))
+            offs[i + 1] = offs[i] + len(ids)
+        tokens = np.concatenate(toks) if toks else np.zeros(0, np.int32)
+        return cls(torch.from_numpy(tokens), torch.from_numpy(offs), torch.from_numpy(empty))
+
+    @classmethod
+    def synthetic(cls, n_docs, device, seed=5, vocab=50265, min_len=60, max_len=300):
+        """Passage lengths U[min_len, max_len], tokens uniform in [3, vocab) (bench / tests: no corpus text offline)."""
+        g = torch.Generator(device=device).manual_seed(seed)
+        lens = torch.randint(min_len, max_len + 1, (n_docs,), generator=g, device=device)
+        offsets = torch.zeros(n_docs + 1, dtype=torch.int64, device=device)
+        offsets[1:] = torch.cumsum(lens, 0)
+        total = int(offsets[-1].item())
+        tokens = torch.randint(3, vocab, (total,), generator=g, device=device, dtype=torch.int32)
+        return cls(tokens, offsets, None)
+
+    def save(self, path):
+        np.savez(path, tokens=self.tokens.cpu().numpy(), offsets=self.offsets.cpu().numpy(),
+                 empty=(np.zeros(0, np.uint8) if self.empty is None else self.empty.cpu().numpy()))
+
+    @classmethod
+    def load(cls, path):
+        z = np.load(path)
+        return cls(torch.from_numpy(z["tokens"]), torch.from_numpy(z["offsets"]), torch.from_numpy(z["empty"]) if z["empty"].size else None)
+
+    # -- the device op -------------------------------------------------------------------------------------
+    def assemble_hop2(self, q_ids, q_mask, doc_ids, hop1_scores=None, out_len=350):
+        """q_ids/q_mask int64 cuda [B, Lq] (the question encoded as `<s> q </s>` right-padded), doc_ids int64 cuda [B, beam],
+        hop1_scores float32 cuda [B, beam] or None (modified in place: -inf for empty passages).
+        -> input_ids, attention_mask int64 cuda [B*beam, out_len]."""
+        dev = q_ids.device
+        B, Lq = q_ids.shape
+        beam = doc_ids.shape[1]
+        q_ids, q_mask, doc_ids = q_ids.contiguous(), q_mask.contiguous(), doc_ids.contiguous()
+        if hop1_scores is not None and not hop1_scores.is_contiguous():
+            raise ValueError("hop1_scores must be contiguous (it is updated in place)")
+        ids = torch.empty((B * beam, out_len), dtype=torch.int64, device=dev)
+        mask = torch.empty_like(ids)
+        vp = ctypes.c_void_p
+        _lib.check(_lib.lib().mdr_assemble_hop2(vp(q_ids.data_ptr()), vp(q_mask.data_ptr()), B, Lq, vp(doc_ids.data_ptr()), beam, vp(self.tokens.data_ptr()),
+                                                vp(self.offsets.data_ptr()), vp(self.empty.data_ptr() if self.empty is not None else None), self.n_docs,
+                                                vp(hop1_scores.data_ptr() if hop1_scores is not None else None), out_len, self.bos_id, self.eos_id,
+                                                self.pad_id, vp(ids.data_ptr()), vp(mask.data_ptr()), _lib.current_stream_ptr(dev)))
+        return ids, mask

@@ -48,6 +48,9 @@ def build_parser():
     p.add_argument("--save-path", type=str, default="")
     p.add_argument("--stop-drop", default=0, type=float)
     p.add_argument("--hnsw", action="store_true")
+    # extension (not in the reference): build the hop-2 inputs on the device from a token arena of the corpus
+    # (tokenised once, cached next to the corpus dict) instead of host dict lookups + tokenizer between the hops
+    p.add_argument("--hop2-on-device", action="store_true")
     return p
 
 
@@ -137,6 +140,19 @@ def main(argv=None, tokenizer=None):
     id2doc = mhop.load_corpus_dict(args.corpus_dict)
     logger.info(f"Corpus size {len(id2doc)}")
 
+    arena = None
+    if args.hop2_on_device:
+        from .arena import TokenArena
+        cache = args.corpus_dict + ".arena.npz"
+        if os.path.exists(cache):
+            arena = TokenArena.load(cache)
+        else:
+            logger.info("Tokenising the corpus once for device-side hop-2 assembly...")
+            arena = TokenArena.from_corpus(id2doc, tokenizer, roberta="roberta" in args.model_name, max_tokens=args.max_q_sp_len)
+            if rank == 0:
+                arena.save(cache)
+        arena = arena.to(torch.device("cuda"))
+
     logger.info("Encoding questions and searching")
     questions = [mhop.strip_question(it["question"]) for it in ds_items]
     metrics, retrieval_outputs = [], []
@@ -148,11 +164,17 @@ def main(argv=None, tokenizer=None):
             enc = move_to_cuda(dict(_tokenize(tokenizer, batch_q, None, args.max_q_len)))
             q_embeds = model.encode_q(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids", None))
             D, I = index.search(q_embeds, args.beam_size)
-            D, I = D.cpu().numpy(), I.cpu().numpy()
-
-            pairs = mhop.build_hop2_pairs(batch_q, D, I, id2doc, roberta=roberta)
-            enc2 = move_to_cuda(dict(_tokenize(tokenizer, None, pairs, args.max_q_sp_len)))
-            q_sp_embeds = model.encode_q(enc2["input_ids"], enc2["attention_mask"], enc2.get("token_type_ids", None))
+            if arena is not None:
+                # questions re-encoded without the hop-1 length cap so the pair sees the same tokens the tokenizer would
+                qfull = move_to_cuda(dict(_tokenize(tokenizer, batch_q, None, args.max_q_sp_len)))
+                ids2, mask2 = arena.assemble_hop2(qfull["input_ids"], qfull["attention_mask"], I, D, args.max_q_sp_len)
+                q_sp_embeds = model.encode_q(ids2, mask2, None)
+                D, I = D.cpu().numpy(), I.cpu().numpy()
+            else:
+                D, I = D.cpu().numpy(), I.cpu().numpy()
+                pairs = mhop.build_hop2_pairs(batch_q, D, I, id2doc, roberta=roberta)
+                enc2 = move_to_cuda(dict(_tokenize(tokenizer, None, pairs, args.max_q_sp_len)))
+                q_sp_embeds = model.encode_q(enc2["input_ids"], enc2["attention_mask"], enc2.get("token_type_ids", None))
             D_, I_ = index.search(q_sp_embeds, args.beam_size)
             D_, I_ = D_.cpu().numpy(), I_.cpu().numpy()
 

@@ -123,7 +123,7 @@ class SyntheticTwoHop:
     """One `step()` = one batch of questions through hop-1 encode -> search -> hop-2 input assembly ->
     hop-2 encode -> search -> path ranking, without leaving the device. Token ids follow SURVEY.md
     §8(d): uniform in [3, vocab), <s>=0 first, </s>=2 last, pad 1, question lengths U[8,40], passage
-    lengths U[60,300]; the hop-2 passage tokens are a deterministic function of the hop-1 doc id."""
+    lengths U[60,300]; hop-2 inputs are gathered from a synthetic token arena by the hop-1 doc ids."""
 
     VOCAB = 50265
 
@@ -147,34 +147,19 @@ class SyntheticTwoHop:
         self.table = torch.randn((1024, dim), generator=g, device=device)
         self.planted_rows = planted_rows
         self.encoder = None
+        self.arena = None
         if use_encoder:
+            from .arena import TokenArena
             from .retriever import RobertaRetriever
             self.encoder = RobertaRetriever.random_init(device=device, seed=3)
+            self.arena = TokenArena.synthetic(int(index.ntotal), device, seed=5, vocab=self.VOCAB)
         self._ev = []
         self._search_ev = []
 
-    # -- synthetic stand-ins for the text side ---------------------------------------------------------
-    def _hop2_inputs(self, I):
-        """<s> q </s></s> doc </s> with longest-first truncation to max_q_sp_len, assembled on device."""
-        B, beam, L = self.B, self.beam, self.Lsp
-        doc = I.reshape(-1)  # [B*beam]
-        qlen = self.q_len.repeat_interleave(beam)  # includes <s> and </s>
-        dlen = 60 + (doc * 2654435761 % 241)  # U[60,300] by doc id
-        total = qlen + 1 + dlen + 1
-        over = (total - L).clamp(min=0)
-        dlen = dlen - over  # the passage is always the longer segment here -> longest-first trims it
-        pos = torch.arange(L, device=self.device)[None, :]
-        q_rep = self.q_ids.repeat_interleave(beam, 0)
-        q_pad = torch.nn.functional.pad(q_rep, (0, L - self.Lq), value=1)
-        dstart = (qlen + 1)[:, None]
-        dtok = 3 + ((doc[:, None] * 1000003 + (pos - dstart) * 7919) % (self.VOCAB - 3))
-        ids = torch.where(pos < qlen[:, None], q_pad, torch.ones_like(q_pad))
-        ids = torch.where(pos == qlen[:, None], torch.full_like(ids, 2), ids)
-        in_doc = (pos >= dstart) & (pos < dstart + dlen[:, None])
-        ids = torch.where(in_doc, dtok, ids)
-        ids = torch.where(pos == dstart + dlen[:, None], torch.full_like(ids, 2), ids)
-        mask = (pos <= dstart + dlen[:, None]).long()
-        return ids, mask
+    # -- hop-2 inputs: assembled on the device from the (synthetic) token arena -----------------------------
+    def _hop2_inputs(self, I, D=None):
+        """`<s> q </s></s> passage </s>` with longest-first truncation to max_q_sp_len (mdr_assemble_hop2)."""
+        return self.arena.assemble_hop2(self.q_ids, self.q_mask, I, D, self.Lsp)
 
     def _encode(self, ids, mask):
         if self.world > 1:
@@ -214,7 +199,7 @@ class SyntheticTwoHop:
         D, I = self._search(q, self.beam)
         ev.append(self._mark())
         if self.use_encoder:
-            ids, mask = self._hop2_inputs(I)
+            ids, mask = self._hop2_inputs(I, D)
             ev.append(self._mark())
             q2 = self._encode(ids, mask)
         else:

@@ -28,7 +28,9 @@ class RobertaToyTokenizer:
                 ia.pop()
         return [0] + ia + [2] + ([2] + ib + [2] if ib is not None else [])
 
-    def __call__(self, a, b=None, text_pair=None, max_length=None, padding=False, truncation=True, return_tensors=None):
+    def __call__(self, a, b=None, text_pair=None, max_length=None, padding=False, truncation=True, return_tensors=None, add_special_tokens=True):
+        if not add_special_tokens:
+            return {"input_ids": self._ids(a)}
         b = b if b is not None else text_pair
         single = isinstance(a, str)
         A = [a] if single else list(a)
@@ -84,6 +86,12 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys):
                                               "--max-q-len", "12", "--max-q-sp-len", "40"], tokenizer=tok)
     lines = out.read_text().strip().split("\n")
     assert len(lines) == 23 and len(metrics) == 23
+    # --hop2-on-device (token arena + mdr_assemble_hop2) must reproduce the host-tokenised run exactly
+    out2 = tmp_path / "paths_dev.jsonl"
+    metrics2, recs2 = eval_mhop_retrieval.main([str(data), path, str(save / "id2doc.json"), str(ckpt), "--batch-size", "10", "--beam-size", "3",
+                                                "--topk", "4", "--model-name", str(cfg_dir), "--gpu", "--save-path", str(out2),
+                                                "--max-q-len", "12", "--max-q-sp-len", "40", "--hop2-on-device"], tokenizer=tok)
+    assert out2.read_text() == out.read_text() and metrics2 == metrics
     rec = json.loads(lines[0])
     assert list(rec.keys()) == ["_id", "question", "candidate_chains"] and rec["question"].endswith("?")
     assert len(rec["candidate_chains"]) == 4 and set(rec["candidate_chains"][0][0].keys()) == {"title", "text"}
