@@ -35,7 +35,7 @@ extern "C" {
 #define MDR_E_WORKSPACE (-4) /* workspace too small: call the matching *_workspace_bytes first */
 #define MDR_E_STATE (-5)    /* handle in the wrong state (e.g. search on an empty encoder) */
 
-#define MDR_KMAX 2048       /* largest k accepted by mdr_index_search */
+#define MDR_KMAX 1024       /* largest k accepted by mdr_index_search */
 
 /* element types of caller-side arrays */
 #define MDR_DT_F32 0
@@ -44,7 +44,7 @@ extern "C" {
 
 /* index storage formats */
 #define MDR_STORE_F32X2H 0  /* fp32-accurate: each element kept as an fp16 (hi, lo) pair = 4 bytes  */
-#define MDR_STORE_BF16 1    /* 2 bytes per element, scores exact w.r.t. the bf16-rounded corpus     */
+#define MDR_STORE_BF16 1    /* rows rounded to bf16 (RNE), 2 bytes per element; scores exact w.r.t. the rounded rows */
 
 const char* mdr_last_error(void);
 const char* mdr_version(void);

@@ -40,6 +40,8 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short ushort8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64;
 
 constexpr int kRowBlock = 16;          // corpus rows per MFMA tile
@@ -90,7 +92,15 @@ template <>
 __device__ inline float load_as_f32<_Float16>(const _Float16* p) { return (float)*p; }
 
 // one thread per (row, 8-column group); rows [n_valid, n_total) are written as zeros (padding)
-template <typename T>
+__device__ inline unsigned short f32_to_bf16_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ inline float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// BF = false: F32X2H planes (fp16 hi + fp16 lo);  BF = true: one plane of bf16 values (dst_lo unused)
+template <typename T, bool BF>
 __global__ void __launch_bounds__(256) convert_to_frag_kernel(const T* __restrict__ src, long long n_valid, long long n_total,
                                                               int d, long long row0, char* __restrict__ dst_hi, char* __restrict__ dst_lo,
                                                               int* __restrict__ flags) {
@@ -101,26 +111,36 @@ __global__ void __launch_bounds__(256) convert_to_frag_kernel(const T* __restric
     int gi = (int)(idx - r * gpr);
     if (r >= n_total) return;
     half8 h, l;
+    ushort8 hb;  // bf16 bit patterns (BF): kept in an integer vector, element-wise bit_cast of half8 lanes is avoided
     bool bad = false;
     if (r < n_valid) {
         const T* p = src + r * (long long)d + gi * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float x = load_as_f32<T>(p + j);
-            if (!(fabsf(x) <= 32768.0f)) bad = true;
-            _Float16 hh = (_Float16)x;
-            float res = x - (float)hh;
-            h[j] = hh;
-            l[j] = (_Float16)(res * kLoScale);
+            if (BF) {
+                if (!(fabsf(x) <= 3.0e38f)) bad = true;
+                hb[j] = f32_to_bf16_rne(x);
+            } else {
+                if (!(fabsf(x) <= 32768.0f)) bad = true;
+                _Float16 hh = (_Float16)x;
+                float res = x - (float)hh;
+                h[j] = hh;
+                l[j] = (_Float16)(res * kLoScale);
+            }
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { h[j] = (_Float16)0.f; l[j] = (_Float16)0.f; }
+        for (int j = 0; j < 8; ++j) { h[j] = (_Float16)0.f; l[j] = (_Float16)0.f; hb[j] = 0; }
     }
     if (bad) atomicOr(flags, 1);
     size_t off = frag_offset(row0 + r, gi * 8, nkb);
-    *(half8*)(dst_hi + off) = h;
-    *(half8*)(dst_lo + off) = l;
+    if (BF) {
+        *(ushort8*)(dst_hi + off) = hb;
+    } else {
+        *(half8*)(dst_hi + off) = h;
+        *(half8*)(dst_lo + off) = l;
+    }
 }
 
 // one wave per row: flags[2] (as float bits) = max over rows of sum(x^2)   (non-negative floats order like ints)
@@ -138,7 +158,7 @@ __global__ void __launch_bounds__(256) row_norm2_max_kernel(const T* __restrict_
 
 // one wave per query: bound[q] = c * |q| * max_row|x| + eps  (0 for padding queries)
 __global__ void __launch_bounds__(256) query_bound_kernel(const float* __restrict__ q, int nq, int nq_pad, int d, const int* __restrict__ flags,
-                                                          float* __restrict__ bound) {
+                                                          float c, float* __restrict__ bound) {
     const int lane = threadIdx.x & 63;
     int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= nq_pad) return;
@@ -147,7 +167,7 @@ __global__ void __launch_bounds__(256) query_bound_kernel(const float* __restric
         for (int c = lane; c < d; c += 64) { float x = q[(size_t)i * d + c]; s += x * x; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) bound[i] = i < nq ? 1.2e-3f * sqrtf(s) * sqrtf(__int_as_float(flags[2])) * 1.0001f + 1e-4f : 0.f;
+    if (lane == 0) bound[i] = i < nq ? c * sqrtf(s) * sqrtf(__int_as_float(flags[2])) * 1.0001f + 1e-4f : 0.f;
 }
 
 // ---- wave-level candidate list maintenance -----------------------------------------------------------
@@ -391,7 +411,13 @@ constexpr int kSampleStages = 4;    // super-blocks per workgroup the sample pas
 // MODE 1 (main pass):   start from gmax, score every row, append rows with s_hi >= known - 2B to this wave's
 //         PRIVATE candidate list (slot from a ballot prefix: no returning atomic, so nothing ever waits on
 //         vmcnt and the corpus DMA is never drained), tighten `known` with the wave's own maxima.
-template <int NKB, int MODE>
+template <bool BF>
+__device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) {
+    if (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <int NKB, int MODE, bool BF>
 __global__ void __launch_bounds__(512, 2)
 mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, const char* __restrict__ Qhi, const float* __restrict__ qbound, int nq,
                    int q_base, unsigned* __restrict__ gmax /* [nq] ordered(max s_hi) */, u64* __restrict__ cand /* [waves][kWaveCandCap] */,
@@ -482,10 +508,10 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
                 x10[kb % PF] = *(const half8*)(p + (NKB + kb + PF) * kFragBytes);
                 x11[kb % PF] = *(const half8*)(p + (NKB + HK + kb + PF) * kFragBytes);
             }
-            a00 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c00, qh[kb], a00, 0, 0, 0);
-            a01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c01, qh[HK + kb], a01, 0, 0, 0);
-            a10 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c10, qh[kb], a10, 0, 0, 0);
-            a11 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c11, qh[HK + kb], a11, 0, 0, 0);
+            a00 = mfma16<BF>(c00, qh[kb], a00);
+            a01 = mfma16<BF>(c01, qh[HK + kb], a01);
+            a10 = mfma16<BF>(c10, qh[kb], a10);
+            a11 = mfma16<BF>(c11, qh[HK + kb], a11);
         }
         __builtin_amdgcn_sched_group_barrier(0x100, 4 * PF, 0);
 #pragma unroll
@@ -532,6 +558,7 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
 
 // exact re-scoring of the screen kernel's candidates: 16 lanes per (query, row), fp32 FMA on both planes;
 // one 256-thread block per source wave list, 16 candidates in flight per block
+template <bool BF>
 __global__ void __launch_bounds__(256)
 mips_refine_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, const u64* __restrict__ cand,
                    const int* __restrict__ cand_cnt, u64* __restrict__ best) {
@@ -548,11 +575,17 @@ mips_refine_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, i
         for (int pc = sub; pc < nkb * 4; pc += 16) {  // piece = (k-block, 8-column group)
             const int kb = pc >> 2, g = pc & 3;
             const size_t off = base + (size_t)kb * kFragBytes + (size_t)g * 256;
-            const half8 h = *(const half8*)(Xhi + off);
-            const half8 l = *(const half8*)(Xlo + off);
             const float* qp = q + (size_t)qi * d + kb * 32 + g * 8;
+            if (BF) {
+                const ushort8 hb = *(const ushort8*)(Xhi + off);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc = fmaf((float)h[j] + (float)l[j] * kLoInv, qp[j], acc);
+                for (int j = 0; j < 8; ++j) acc = fmaf(bf16_bits_to_f32(hb[j]), qp[j], acc);
+            } else {
+                const half8 h = *(const half8*)(Xhi + off);
+                const half8 l = *(const half8*)(Xlo + off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = fmaf((float)h[j] + (float)l[j] * kLoInv, qp[j], acc);
+            }
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -562,10 +595,12 @@ mips_refine_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, i
 
 // ---- generic kernel: any d (multiple of 32), fp32 FMA on the reconstructed values ------------------
 // Correctness reference on the device and fallback for shapes the stream kernel does not cover.
+template <bool BF>
 __global__ void __launch_bounds__(256)
 mips_generic_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, long long n_rows, int n_rb, int nkb, const float* __restrict__ q, int nq,
-                    u64* __restrict__ cand, int* __restrict__ cand_cnt, u64* __restrict__ cand_kth, int k) {
+                    u64* __restrict__ cand, int* __restrict__ cand_cnt, u64* __restrict__ cand_kth, int k, const int* __restrict__ run_if) {
     __shared__ int lds_cnt[kGenericQ];
+    if (run_if && *run_if == 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int d = nkb * 32;
@@ -592,10 +627,16 @@ mips_generic_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const size_t e = blk + (size_t)kb * kFragBytes + (size_t)((4 * g4 + r) + 16 * gp) * 16;
-                        half8 h = *(const half8*)(Xhi + e);
-                        half8 l = *(const half8*)(Xlo + e);
+                        if (BF) {
+                            const ushort8 hb = *(const ushort8*)(Xhi + e);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[r] = fmaf((float)h[j] + (float)l[j] * kLoInv, qv[j], acc[r]);
+                            for (int j = 0; j < 8; ++j) acc[r] = fmaf(bf16_bits_to_f32(hb[j]), qv[j], acc[r]);
+                        } else {
+                            half8 h = *(const half8*)(Xhi + e);
+                            half8 l = *(const half8*)(Xlo + e);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[r] = fmaf((float)h[j] + (float)l[j] * kLoInv, qv[j], acc[r]);
+                        }
                     }
                 }
             }
@@ -642,8 +683,9 @@ __device__ inline int block_sum_256(int v, int* red) {
 // general k: merge G per-workgroup lists of one query group. One 256-thread block per query.
 __global__ void __launch_bounds__(256)
 merge_lists_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_cnt, const u64* __restrict__ cand_kth, int G, int qcap,
-                   int cap, int k, float* __restrict__ D, long long* __restrict__ I, long long id_offset) {
+                   int cap, int k, float* __restrict__ D, long long* __restrict__ I, long long id_offset, const int* __restrict__ run_if) {
     __shared__ u64 keys[kMergeLds];
+    if (run_if && *run_if == 0) return;
     __shared__ u64 sel[kKMax];
     __shared__ int red[4];
     __shared__ u64 s_u64[4];
@@ -806,13 +848,14 @@ int grow(mdr_index* h, long long need_rows, hipStream_t st) {
     const size_t used = (size_t)pad32(h->ntotal) * plane_bytes_per_row(h);
     char* planes[2] = {nullptr, nullptr};
     char* old[2] = {h->hi, h->lo};
-    for (int i = 0; i < 2; ++i) {
+    const int nplanes = h->storage == MDR_STORE_BF16 ? 1 : 2;
+    for (int i = 0; i < nplanes; ++i) {
         MDR_HIP_TRY(hipMalloc((void**)&planes[i], nbytes));
         if (used) MDR_HIP_TRY(hipMemcpyAsync(planes[i], old[i], used, hipMemcpyDeviceToDevice, st));
         MDR_HIP_TRY(hipMemsetAsync(planes[i] + used, 0, nbytes - used, st));
     }
     MDR_HIP_TRY(hipStreamSynchronize(st));
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < nplanes; ++i)
         if (old[i]) MDR_HIP_TRY(hipFree(old[i]));
     h->hi = planes[0];
     h->lo = planes[1];
@@ -821,19 +864,22 @@ int grow(mdr_index* h, long long need_rows, hipStream_t st) {
 }
 
 template <typename T>
-int launch_convert(const T* src_dev, long long n_valid, long long n_total, int d, long long row0, char* dst_hi, char* dst_lo, int* flags,
+int launch_convert(bool bf, const T* src_dev, long long n_valid, long long n_total, int d, long long row0, char* dst_hi, char* dst_lo, int* flags,
                    hipStream_t st) {
     long long threads = n_total * (d / 8);
     if (threads == 0) return MDR_OK;
     long long blocks = (threads + 255) / 256;
-    hipLaunchKernelGGL(convert_to_frag_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, src_dev, n_valid, n_total, d, row0, dst_hi, dst_lo, flags);
+    if (bf)
+        hipLaunchKernelGGL((convert_to_frag_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, st, src_dev, n_valid, n_total, d, row0, dst_hi, dst_lo, flags);
+    else
+        hipLaunchKernelGGL((convert_to_frag_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st, src_dev, n_valid, n_total, d, row0, dst_hi, dst_lo, flags);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }
 
 template <typename T>
 int launch_add(mdr_index* h, const T* src_dev, long long n, long long row0, hipStream_t st) {
-    int rc = launch_convert(src_dev, n, n, h->d, row0, h->hi, h->lo, h->flags, st);
+    int rc = launch_convert(h->storage == MDR_STORE_BF16, src_dev, n, n, h->d, row0, h->hi, h->lo, h->flags, st);
     if (rc) return rc;
     hipLaunchKernelGGL(row_norm2_max_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src_dev, n, h->d, h->flags);
     MDR_HIP_TRY(hipGetLastError());
@@ -851,16 +897,17 @@ int add_any(mdr_index* h, const void* src_dev, int dtype, long long n, long long
 
 size_t elem_size(int dtype) { return dtype == MDR_DT_F32 ? 4 : 2; }
 
-bool stream_kernel_supports(const mdr_index* h, int k) { return h->d == 768 && k <= 128; }
+bool is_bf16(const mdr_index* h) { return h->storage == MDR_STORE_BF16; }
+bool stream_kernel_supports(const mdr_index* h, int k) { return !is_bf16(h) && h->d == 768 && k <= 128; }
 bool screen_kernel_supports(const mdr_index* h, int k) { return h->d == 768 && k == 1; }
 
 enum Path { PATH_GENERIC = 1, PATH_STREAM = 2, PATH_SCREEN = 3 };
 
 struct SearchPlan {
     int path;
-    int qgroup;  // queries per pass
-    int cap;     // candidate slots per (wg, query) of the list-based kernels
-    int G;       // workgroups
+    int G;    // workgroups of the stream / screen kernels
+    int Gg;   // workgroups of the generic kernel (when its lists are needed)
+    bool lists_stream, lists_generic;
     size_t off_qhi, off_qlo, off_bound, off_best, off_gmax, off_scand, off_sctl, off_cand, off_cnt, off_kth, total;
 };
 
@@ -869,40 +916,95 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     const int v = h->variant;
     if (v == PATH_GENERIC) p.path = PATH_GENERIC;
     else if (v == PATH_STREAM) p.path = stream_kernel_supports(h, k) ? PATH_STREAM : PATH_GENERIC;
-    else if (screen_kernel_supports(h, k)) p.path = PATH_SCREEN;       // auto or forced screen
+    else if (screen_kernel_supports(h, k)) p.path = PATH_SCREEN;  // auto or forced screen
     else if (stream_kernel_supports(h, k)) p.path = PATH_STREAM;
     else p.path = PATH_GENERIC;
     const long long n_rb = (h->ntotal + 15) / 16;
-    if (p.path != PATH_GENERIC) {
-        p.qgroup = kStreamQ;
-        p.cap = kStreamCap;
-        long long units = p.path == PATH_SCREEN ? (h->ntotal + 31) / 32 : n_rb;
-        p.G = (int)(units < h->num_cus ? (units > 0 ? units : 1) : h->num_cus);
-    } else {
-        p.qgroup = kGenericQ;
-        p.cap = kGenericCap;
-        long long g = (long long)h->num_cus * 2;
-        p.G = (int)(n_rb < g ? (n_rb > 0 ? n_rb : 1) : g);
-    }
-    const int ngroups = (nq + p.qgroup - 1) / p.qgroup;
-    const size_t nq_pad = (size_t)ngroups * p.qgroup;
+    const long long units = p.path == PATH_SCREEN ? (h->ntotal + 31) / 32 : n_rb;
+    p.G = (int)(units < h->num_cus ? (units > 0 ? units : 1) : h->num_cus);
+    const long long gg = (long long)h->num_cus * 2;
+    p.Gg = (int)(n_rb < gg ? (n_rb > 0 ? n_rb : 1) : gg);
+    // which candidate-list workspaces this call can touch (incl. the conditional exact pass behind the screen kernel)
+    p.lists_stream = p.path == PATH_STREAM && k > 1;
+    p.lists_generic = p.path == PATH_GENERIC || (p.path == PATH_SCREEN && is_bf16(h));
     const bool frag = p.path != PATH_GENERIC;
-    const bool lists = !(p.path == PATH_SCREEN || (p.path == PATH_STREAM && k == 1));
-    // the conditional exact pass behind the screen kernel needs the stream kernel's (k == 1) buffers only
+    const size_t nq_pad = (size_t)((nq + kStreamQ - 1) / kStreamQ) * kStreamQ;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
     p.off_qhi = take(frag ? nq_pad * h->d * 2 : 0);
-    p.off_qlo = take(frag ? nq_pad * h->d * 2 : 0);
+    p.off_qlo = take(frag && !is_bf16(h) ? nq_pad * h->d * 2 : 0);
     p.off_bound = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
     p.off_best = take((size_t)(nq > 0 ? nq : 1) * 8);
     p.off_gmax = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
     p.off_scand = take(p.path == PATH_SCREEN ? (size_t)p.G * 8 * kWaveCandCap * 8 : 0);  // one private list per wave
     p.off_sctl = take(p.path == PATH_SCREEN ? 256 + (size_t)p.G * 8 * 4 : 0);            // [0] overflow flag, [64..] per-wave counts
-    p.off_cand = take(lists ? (size_t)p.G * p.qgroup * p.cap * 8 : 0);
-    p.off_cnt = take(lists ? (size_t)p.G * p.qgroup * 4 : 0);
-    p.off_kth = take(lists ? (size_t)p.G * p.qgroup * 8 : 0);
+    const size_t lists = p.lists_stream ? (size_t)p.G * kStreamQ * kStreamCap : (p.lists_generic ? (size_t)p.Gg * kGenericQ * kGenericCap : 0);
+    const size_t slots = p.lists_stream ? (size_t)p.G * kStreamQ : (p.lists_generic ? (size_t)p.Gg * kGenericQ : 0);
+    p.off_cand = take(lists * 8);
+    p.off_cnt = take(slots * 4);
+    p.off_kth = take(slots * 8);
     p.total = o + 256;
     return p;
+}
+
+// generic kernel + merge over all queries in groups of kGenericQ; every launch is skipped on the device when *run_if == 0
+template <bool BF>
+int run_generic(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, int k, float* D_dev, long long* I_dev, long long id_offset,
+                const int* run_if, hipStream_t st) {
+    u64* cand = (u64*)(ws + p.off_cand);
+    int* cnt = (int*)(ws + p.off_cnt);
+    u64* kth = (u64*)(ws + p.off_kth);
+    const int n_rb = (int)((h->ntotal + 15) / 16);
+    for (int q0 = 0; q0 < nq; q0 += kGenericQ) {
+        const int nqg = nq - q0 < kGenericQ ? nq - q0 : kGenericQ;
+        MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.Gg * kGenericQ * 4, st));
+        MDR_HIP_TRY(hipMemsetAsync(kth, 0, (size_t)p.Gg * kGenericQ * 8, st));
+        hipLaunchKernelGGL((mips_generic_kernel<BF>), dim3(p.Gg), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, (long long)h->ntotal, n_rb, h->nkb,
+                           q_dev + (size_t)q0 * h->d, nqg, cand, cnt, kth, k, run_if);
+        hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.Gg, kGenericQ, kGenericCap,
+                           k, D_dev + (size_t)q0 * k, I_dev + (size_t)q0 * k, id_offset, run_if);
+        MDR_HIP_TRY(hipGetLastError());
+    }
+    return MDR_OK;
+}
+
+template <bool BF>
+int run_screen(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, const char* qhi, u64* best, hipStream_t st) {
+    constexpr int NKB = 24;
+    const size_t lds_bytes = 3 * (size_t)NKB * 2 * kFragBytes;
+    static bool attr = false;
+    if (!attr) {
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screen_kernel<NKB, 0, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screen_kernel<NKB, 1, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr = true;
+    }
+    float* bound = (float*)(ws + p.off_bound);
+    unsigned* gmax = (unsigned*)(ws + p.off_gmax);
+    u64* scand = (u64*)(ws + p.off_scand);
+    int* sctl = (int*)(ws + p.off_sctl);
+    int* wave_cnt = sctl + 64;
+    const int ngroups = (nq + kStreamQ - 1) / kStreamQ;
+    const int nq_pad = ngroups * kStreamQ;
+    const int n_sb = (int)((h->ntotal + 31) / 32);
+    const size_t qgroup_bytes = (size_t)kStreamQ * h->d * 2;
+    // |q.x - qh.xh| <= c |q| max|x|: fp16 rounding of both operands (2^-10) or bf16 rounding of q only (2^-9; the
+    // stored rows ARE the bf16 values), plus fp32 accumulation slack
+    const float c = BF ? 2.2e-3f : 1.2e-3f;
+    MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
+    MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
+    hipLaunchKernelGGL(query_bound_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)h->flags, c, bound);
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int nqg = nq - gi * kStreamQ < kStreamQ ? nq - gi * kStreamQ : kStreamQ;
+        const char* qg = qhi + gi * qgroup_bytes;
+        hipLaunchKernelGGL((mips_screen_kernel<NKB, 0, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
+                           (const float*)(bound + (size_t)gi * kStreamQ), nqg, gi * kStreamQ, gmax + (size_t)gi * kStreamQ, scand, wave_cnt, sctl);
+        hipLaunchKernelGGL((mips_screen_kernel<NKB, 1, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
+                           (const float*)(bound + (size_t)gi * kStreamQ), nqg, gi * kStreamQ, gmax + (size_t)gi * kStreamQ, scand, wave_cnt, sctl);
+        hipLaunchKernelGGL((mips_refine_kernel<BF>), dim3(p.G * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
+                           (const u64*)scand, (const int*)wave_cnt, best);
+        MDR_HIP_TRY(hipGetLastError());
+    }
+    return MDR_OK;
 }
 
 }  // namespace
@@ -912,7 +1014,7 @@ extern "C" {
 int mdr_index_create(int d, int storage, int device, mdr_index** out) {
     MDR_REQUIRE(out != nullptr, "out is NULL");
     MDR_REQUIRE(d > 0 && d % 32 == 0 && d <= 1024, "d=%d unsupported: must be a multiple of 32, <= 1024", d);
-    MDR_REQUIRE(storage == MDR_STORE_F32X2H, "storage %d not implemented (only MDR_STORE_F32X2H)", storage);
+    MDR_REQUIRE(storage == MDR_STORE_F32X2H || storage == MDR_STORE_BF16, "unknown storage %d", storage);
     int ndev = 0;
     MDR_HIP_TRY(hipGetDeviceCount(&ndev));
     MDR_REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
@@ -996,7 +1098,8 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
         // roll back: the rows stay invisible (ntotal unchanged), the norm bound returns to its previous value
         MDR_HIP_TRY(hipMemcpyAsync(h->flags, before, sizeof(before), hipMemcpyHostToDevice, st));
         MDR_HIP_TRY(hipStreamSynchronize(st));
-        return set_error(MDR_E_RANGE, "add(): a value is non-finite or |x| > 32768, not representable in F32X2H storage; rows were not added");
+        return set_error(MDR_E_RANGE, is_bf16(h) ? "add(): a value is non-finite; rows were not added"
+                                                 : "add(): a value is non-finite or |x| > 32768, not representable in F32X2H storage; rows were not added");
     }
     h->ntotal += n;
     return MDR_OK;
@@ -1004,7 +1107,7 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
 
 int64_t mdr_index_ntotal(const mdr_index* h) { return h ? h->ntotal : 0; }
 int mdr_index_dim(const mdr_index* h) { return h ? h->d : 0; }
-int64_t mdr_index_stream_bytes(const mdr_index* h) { return h ? (int64_t)((h->ntotal + 15) / 16 * 16) * (int64_t)h->d * 4 : 0; }
+int64_t mdr_index_stream_bytes(const mdr_index* h) { return h ? (int64_t)((h->ntotal + 15) / 16 * 16) * (int64_t)h->d * (is_bf16(h) ? 2 : 4) : 0; }
 
 int mdr_index_set_variant(mdr_index* h, int variant) {
     MDR_REQUIRE(h != nullptr, "index handle is NULL");
@@ -1028,14 +1131,15 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
     if (nq == 0) return MDR_OK;
     MDR_REQUIRE(q_dev && D_dev && I_dev, "NULL query/result pointer");
     if (h->variant == PATH_STREAM && !stream_kernel_supports(h, k))
-        return set_error(MDR_E_INVALID, "stream kernel forced but unsupported for d=%d k=%d (needs d=768, k<=128)", h->d, k);
+        return set_error(MDR_E_INVALID, "stream kernel forced but unsupported for d=%d k=%d storage=%d (needs F32X2H, d=768, k<=128)", h->d, k, h->storage);
     if (h->variant == PATH_SCREEN && !screen_kernel_supports(h, k))
         return set_error(MDR_E_INVALID, "screen kernel forced but unsupported for d=%d k=%d (needs d=768, k=1)", h->d, k);
     DeviceGuard g(h->device);
     hipStream_t st = (hipStream_t)stream;
+    long long* I_ll = (long long*)I_dev;
     if (h->ntotal == 0) {
         long long n = (long long)nq * k;
-        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, D_dev, (long long*)I_dev, n);
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, D_dev, I_ll, n);
         MDR_HIP_TRY(hipGetLastError());
         h->last_kernel = "fill_empty_kernel";
         return MDR_OK;
@@ -1044,108 +1148,81 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
     if (!workspace_dev || workspace_bytes < p.total)
         return set_error(MDR_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", p.total, workspace_bytes);
     char* ws = (char*)(((uintptr_t)workspace_dev + 255) & ~(uintptr_t)255);
-    const int n_rb = (int)((h->ntotal + 15) / 16);
-    const int n_sb = (int)((h->ntotal + 31) / 32);
-    u64* best = (u64*)(ws + p.off_best);
-    u64* cand = (u64*)(ws + p.off_cand);
-    int* cnt = (int*)(ws + p.off_cnt);
-    u64* kth = (u64*)(ws + p.off_kth);
-    const int ngroups = (nq + p.qgroup - 1) / p.qgroup;
+    const bool bf = is_bf16(h);
+    int rc;
+    if (p.path == PATH_GENERIC) {
+        rc = bf ? run_generic<true>(h, p, ws, q_dev, nq, k, D_dev, I_ll, id_offset, nullptr, st)
+                : run_generic<false>(h, p, ws, q_dev, nq, k, D_dev, I_ll, id_offset, nullptr, st);
+        h->last_kernel = "mips_generic_kernel";
+        return rc;
+    }
+
     constexpr int NKB = 24;
     const size_t rb_bytes = (size_t)NKB * 2 * kFragBytes;  // one exact-kernel stage == one screen-kernel stage == 48 KiB
-    static bool attr_done[3] = {false, false, false};
+    const int n_rb = (int)((h->ntotal + 15) / 16);
+    const int ngroups = (nq + kStreamQ - 1) / kStreamQ;
+    const size_t qgroup_bytes = (size_t)kStreamQ * h->d * 2;
+    u64* best = (u64*)(ws + p.off_best);
+    char* qhi = ws + p.off_qhi;
+    char* qlo = ws + p.off_qlo;
+    static bool attr_done[2] = {false, false};
+    rc = launch_convert(bf, q_dev, (long long)nq, (long long)ngroups * kStreamQ, h->d, 0, qhi, qlo, h->flags + 1, st);
+    if (rc) return rc;
 
-    if (p.path != PATH_GENERIC) {
-        char* qhi = ws + p.off_qhi;
-        char* qlo = ws + p.off_qlo;
-        int rc = launch_convert(q_dev, (long long)nq, (long long)ngroups * p.qgroup, h->d, 0, qhi, qlo, h->flags + 1, st);
-        if (rc) return rc;
-        const size_t qgroup_bytes = (size_t)p.qgroup * h->d * 2;
-        if (k == 1) {
+    if (k == 1) {
+        MDR_HIP_TRY(hipMemsetAsync(best, 0, (size_t)nq * 8, st));
+        const int* run_if = nullptr;
+        if (p.path == PATH_SCREEN) {
+            rc = bf ? run_screen<true>(h, p, ws, q_dev, nq, qhi, best, st) : run_screen<false>(h, p, ws, q_dev, nq, qhi, best, st);
+            if (rc) return rc;
+            run_if = (const int*)(ws + p.off_sctl);  // exact pass below: only if a candidate list overflowed
+            h->last_kernel = bf ? "mips_screen_kernel<24,1,bf16>" : "mips_screen_kernel<24,1>";
+        } else {
+            h->last_kernel = "mips_stream_kernel<24,0>";
+        }
+        if (!bf) {
             if (!attr_done[0]) {
                 MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_stream_kernel<NKB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * rb_bytes)));
                 attr_done[0] = true;
             }
-            MDR_HIP_TRY(hipMemsetAsync(best, 0, (size_t)nq * 8, st));
-            const int* run_if = nullptr;
-            if (p.path == PATH_SCREEN) {
-                if (!attr_done[2]) {
-                    MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screen_kernel<NKB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * rb_bytes)));
-                    MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screen_kernel<NKB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * rb_bytes)));
-                    attr_done[2] = true;
-                }
-                float* bound = (float*)(ws + p.off_bound);
-                unsigned* gmax = (unsigned*)(ws + p.off_gmax);
-                u64* scand = (u64*)(ws + p.off_scand);
-                int* sctl = (int*)(ws + p.off_sctl);
-                int* wave_cnt = sctl + 64;
-                const int nq_pad = ngroups * p.qgroup;
-                MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
-                MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
-                hipLaunchKernelGGL(query_bound_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)h->flags, bound);
-                for (int gi = 0; gi < ngroups; ++gi) {
-                    int nqg = nq - gi * p.qgroup < p.qgroup ? nq - gi * p.qgroup : p.qgroup;
-                    const char* qg = qhi + gi * qgroup_bytes;
-                    hipLaunchKernelGGL((mips_screen_kernel<NKB, 0>), dim3(p.G), dim3(512), 3 * rb_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
-                                       (const float*)(bound + (size_t)gi * p.qgroup), nqg, gi * p.qgroup, gmax + (size_t)gi * p.qgroup, scand, wave_cnt,
-                                       sctl);
-                    hipLaunchKernelGGL((mips_screen_kernel<NKB, 1>), dim3(p.G), dim3(512), 3 * rb_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
-                                       (const float*)(bound + (size_t)gi * p.qgroup), nqg, gi * p.qgroup, gmax + (size_t)gi * p.qgroup, scand, wave_cnt,
-                                       sctl);
-                    hipLaunchKernelGGL(mips_refine_kernel, dim3(p.G * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
-                                       (const u64*)scand, (const int*)wave_cnt, best);
-                    MDR_HIP_TRY(hipGetLastError());
-                }
-                run_if = sctl;  // the exact pass below runs only if a candidate list overflowed
-                h->last_kernel = "mips_screen_kernel<24,1>";
-            } else {
-                h->last_kernel = "mips_stream_kernel<24,0>";
-            }
             const int Gx = (int)(n_rb < h->num_cus ? n_rb : h->num_cus);
             for (int gi = 0; gi < ngroups; ++gi) {
-                int nqg = nq - gi * p.qgroup < p.qgroup ? nq - gi * p.qgroup : p.qgroup;
+                const int nqg = nq - gi * kStreamQ < kStreamQ ? nq - gi * kStreamQ : kStreamQ;
                 hipLaunchKernelGGL((mips_stream_kernel<NKB, 0>), dim3(Gx), dim3(512), 3 * rb_bytes, st, (const char*)h->hi, (const char*)h->lo,
                                    (long long)h->ntotal, n_rb, (const char*)(qhi + gi * qgroup_bytes), (const char*)(qlo + gi * qgroup_bytes), nqg,
-                                   best + (size_t)gi * p.qgroup, (u64*)nullptr, (int*)nullptr, (u64*)nullptr, 1, run_if);
+                                   best + (size_t)gi * kStreamQ, (u64*)nullptr, (int*)nullptr, (u64*)nullptr, 1, run_if);
                 MDR_HIP_TRY(hipGetLastError());
             }
-            hipLaunchKernelGGL(finalize_top1_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, (const u64*)best, nq, D_dev, (long long*)I_dev,
-                               (long long)id_offset);
-            MDR_HIP_TRY(hipGetLastError());
-        } else {
-            const size_t lds_bytes = 3 * rb_bytes + kStreamQ * sizeof(int);
-            if (!attr_done[1]) {
-                MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_stream_kernel<NKB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-                attr_done[1] = true;
-            }
-            for (int gi = 0; gi < ngroups; ++gi) {
-                int nqg = nq - gi * p.qgroup < p.qgroup ? nq - gi * p.qgroup : p.qgroup;
-                MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * p.qgroup * 4, st));
-                MDR_HIP_TRY(hipMemsetAsync(kth, 0, (size_t)p.G * p.qgroup * 8, st));
-                hipLaunchKernelGGL((mips_stream_kernel<NKB, 1>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (const char*)h->lo,
-                                   (long long)h->ntotal, n_rb, (const char*)(qhi + gi * qgroup_bytes), (const char*)(qlo + gi * qgroup_bytes), nqg,
-                                   (u64*)nullptr, cand, cnt, kth, k, (const int*)nullptr);
-                MDR_HIP_TRY(hipGetLastError());
-                hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.G, p.qgroup,
-                                   p.cap, k, D_dev + (size_t)gi * p.qgroup * k, (long long*)I_dev + (size_t)gi * p.qgroup * k, (long long)id_offset);
-                MDR_HIP_TRY(hipGetLastError());
-            }
-            h->last_kernel = "mips_stream_kernel<24,1>";
         }
-    } else {
-        for (int gi = 0; gi < ngroups; ++gi) {
-            int nqg = nq - gi * p.qgroup < p.qgroup ? nq - gi * p.qgroup : p.qgroup;
-            MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * p.qgroup * 4, st));
-            MDR_HIP_TRY(hipMemsetAsync(kth, 0, (size_t)p.G * p.qgroup * 8, st));
-            hipLaunchKernelGGL(mips_generic_kernel, dim3(p.G), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, (long long)h->ntotal, n_rb, h->nkb,
-                               q_dev + (size_t)gi * p.qgroup * h->d, nqg, cand, cnt, kth, k);
-            MDR_HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.G, p.qgroup, p.cap,
-                               k, D_dev + (size_t)gi * p.qgroup * k, (long long*)I_dev + (size_t)gi * p.qgroup * k, (long long)id_offset);
-            MDR_HIP_TRY(hipGetLastError());
-        }
-        h->last_kernel = "mips_generic_kernel";
+        hipLaunchKernelGGL(finalize_top1_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, (const u64*)best, nq, D_dev, I_ll, (long long)id_offset);
+        MDR_HIP_TRY(hipGetLastError());
+        if (bf)  // bf16 storage has no exact MFMA pass: the overflow fallback is the generic kernel, overwriting D/I
+            return run_generic<true>(h, p, ws, q_dev, nq, 1, D_dev, I_ll, id_offset, run_if, st);
+        return MDR_OK;
     }
+
+    // 2 <= k <= 128, F32X2H: exact stream kernel with candidate lists
+    u64* cand = (u64*)(ws + p.off_cand);
+    int* cnt = (int*)(ws + p.off_cnt);
+    u64* kth = (u64*)(ws + p.off_kth);
+    const size_t lds_bytes = 3 * rb_bytes + kStreamQ * sizeof(int);
+    if (!attr_done[1]) {
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_stream_kernel<NKB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_done[1] = true;
+    }
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int nqg = nq - gi * kStreamQ < kStreamQ ? nq - gi * kStreamQ : kStreamQ;
+        MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * kStreamQ * 4, st));
+        MDR_HIP_TRY(hipMemsetAsync(kth, 0, (size_t)p.G * kStreamQ * 8, st));
+        hipLaunchKernelGGL((mips_stream_kernel<NKB, 1>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (const char*)h->lo, (long long)h->ntotal,
+                           n_rb, (const char*)(qhi + gi * qgroup_bytes), (const char*)(qlo + gi * qgroup_bytes), nqg, (u64*)nullptr, cand, cnt, kth, k,
+                           (const int*)nullptr);
+        MDR_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.G, kStreamQ, kStreamCap, k,
+                           D_dev + (size_t)gi * kStreamQ * k, I_ll + (size_t)gi * kStreamQ * k, (long long)id_offset, (const int*)nullptr);
+        MDR_HIP_TRY(hipGetLastError());
+    }
+    h->last_kernel = "mips_stream_kernel<24,1>";
     return MDR_OK;
 }
 
