@@ -695,6 +695,49 @@ __global__ void __launch_bounds__(512) attention_kernel(const _Float16* __restri
     }
 }
 
+// Last layer: only the CLS row of each sequence feeds the projection head, so its attention needs ONE query per
+// (sequence, head). One wave per (sequence, head): scores over the keys (lane = key), softmax, then lane = feature.
+__global__ void __launch_bounds__(64) attention_cls_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
+                                                           _Float16* __restrict__ ctx_cls /* [B, H] */) {
+    __shared__ float p_s[512];
+    __shared__ float q_s[64];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int start = cu[b], len = cu[b + 1] - start;
+    if (len <= 0) return;
+    const int H3 = 3 * H;
+    q_s[lane] = (float)qkv[(size_t)start * H3 + h * 64 + lane] * 0.125f;
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int key = lane; key < len; key += 64) {
+        const _Float16* kp = qkv + (size_t)(start + key) * H3 + H + h * 64;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const half8 kv = *(const half8*)(kp + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = fmaf((float)kv[j], q_s[c * 8 + j], s);
+        }
+        p_s[key] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int key = lane; key < len; key += 64) {
+        const float e = exp2f((p_s[key] - mx) * 1.4426950408889634f);
+        p_s[key] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const float inv = 1.f / sum;
+    float o = 0.f;
+    for (int key = 0; key < len; ++key)  // P rounded to fp16 like the MFMA path (apex O1: probs enter the PV matmul as fp16)
+        o = fmaf((float)(_Float16)(p_s[key] * inv), (float)qkv[(size_t)(start + key) * H3 + 2 * H + h * 64 + lane], o);
+    ctx_cls[(size_t)b * H + h * 64 + lane] = (_Float16)o;
+}
+
 template <int NT>
 constexpr int attention_lds_bytes() { return NT * 16 * 128 + 64 * (NT * 16 + 8) * 2; }
 
@@ -984,6 +1027,24 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
         const mdr_encoder::Layer& Ly = h->layers[i];
         rc = launch_gemm<EPI_BIAS_F16>(w.h16, H, Ly.wqkv, Ly.bqkv, Tcap, w.total, 3 * H, H, w.qkv, 3 * H, nullptr, 0, Test, ncu, st);
         if (rc) return rc;
+        if (i + 1 == c.layers) {
+            // ---- last layer: everything after the K/V projection only for the CLS rows ([B, H] instead of [T, H]) ----
+            hipLaunchKernelGGL(gather_cls_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, (const _Float16*)w.h16, (const int*)w.cu, B, H, w.cls16);
+            hipLaunchKernelGGL(attention_cls_kernel, dim3(c.heads, B), dim3(64), 0, st, (const _Float16*)w.qkv, (const int*)w.cu, H, w.ctx);
+            MDR_HIP_TRY(hipGetLastError());
+            rc = launch_gemm<EPI_BIAS_RES_F32>(w.ctx, H, Ly.wo, Ly.bo, B, nullptr, H, H, w.clspre, H, w.cls16, H, B, ncu, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, (const _Float16*)nullptr, B, (const int*)nullptr,
+                               H, (const float*)Ly.ln1_g, (const float*)Ly.ln1_b, c.ln_eps, w.cls16, (float*)nullptr);
+            rc = launch_gemm<EPI_BIAS_GELU_F16>(w.cls16, H, Ly.w1, Ly.b1, B, nullptr, F, H, w.ffn, F, nullptr, 0, B, ncu, st);
+            if (rc) return rc;
+            rc = launch_gemm<EPI_BIAS_RES_F32>(w.ffn, F, Ly.w2, Ly.b2, B, nullptr, H, F, w.clspre, H, w.cls16, H, B, ncu, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, (const _Float16*)nullptr, B, (const int*)nullptr,
+                               H, (const float*)Ly.ln2_g, (const float*)Ly.ln2_b, c.ln_eps, w.cls16, (float*)nullptr);
+            MDR_HIP_TRY(hipGetLastError());
+            break;
+        }
         if (L <= 128) rc = launch_attention<8>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         else if (L <= 384) rc = launch_attention<24>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         else rc = launch_attention<32>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
@@ -1001,7 +1062,6 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
                            (const int*)w.total, H, (const float*)Ly.ln2_g, (const float*)Ly.ln2_b, c.ln_eps, w.h16, (float*)nullptr);
         MDR_HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(gather_cls_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, (const _Float16*)w.h16, (const int*)w.cu, B, H, w.cls16);
     rc = launch_gemm<EPI_BIAS_F32>(w.cls16, H, h->wproj, h->bproj, B, nullptr, H, H, w.clspre, H, nullptr, 0, B, ncu, st);
     if (rc) return rc;
     hipLaunchKernelGGL(layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, (const _Float16*)nullptr, B, (const int*)nullptr, H, (const float*)h->lnp_g,
