@@ -392,18 +392,19 @@ gemm_f16_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
 // the loads of the next tile's first stages are issued during the current tile's last K-steps, so the
 // global_load_lds pipeline never empties; the epilogue (bias from LDS, no register-destination VMEM load that
 // would make the compiler wait on the in-flight DMA) runs under the next tile's loads.
-// Tile 256x128x64, 8 waves as 4x2 (wave 64x64), 3-slot ring (2 stages in flight), bias vector staged in LDS once.
+// Tile 256x128x64, 8 waves as 4x2 (wave 64x64), 3-slot ring (2 batches in flight), bias vector staged in LDS once.
+// Measured alternatives (round 1, hop-2 shapes): 256x256 with a 2-slot ring 8.3 ms vs 5.8 ms (one batch in flight is not
+// enough), 256x256 with four K=32 slots 7.4 ms (twice the barriers), burst-issued DMA +2 %, n-fastest tile order +9 %.
 // The residual of EPI_BIAS_RES_F32 is NOT added here: the LayerNorm kernel that follows adds it (res argument).
-using GemmP = GemmCfg<256, 128, 4, 2, 3>;
-static_assert(GemmP::MT == 4 && GemmP::NT == 4 && GemmP::A_CHUNKS == 4 && GemmP::W_CHUNKS <= 4, "the pinned K-step below is written for this shape");
+using GemmP = GemmCfg<256, 128, 4, 2, 3>;   // 3 slots of 48 KiB: two batches in flight
 constexpr int kPersistBiasMax = 3072;  // floats of bias kept in LDS behind the ring (12 KiB)
 
-template <int EPI>
-__global__ void __launch_bounds__(GemmP::THREADS)
+template <int EPI, typename C>
+__global__ void __launch_bounds__(C::THREADS)
 gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M_cap,
                     const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo, int gn) {
-    using C = GemmP;
-    constexpr int MT = C::MT, NT = C::NT;
+    static_assert(C::MT == 4 && (C::NT == 4 || C::NT == 8) && C::A_CHUNKS == 4 && C::W_CHUNKS <= 4, "the pinned K-step below is written for these shapes");
+    constexpr int MT = C::MT, NT = C::NT, SLOTS = C::STAGES, AHEAD = SLOTS - 1;  // batches issued ahead of the one being computed
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* lds_bias = (float*)(lds + C::LDS_BYTES);
     const int M = M_dev ? min(*M_dev, M_cap) : M_cap;
@@ -472,9 +473,9 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bias loads above, before any DMA is in flight
 #pragma unroll
-    for (int pre = 0; pre < 2; ++pre) {
+    for (int pre = 0; pre < AHEAD; ++pre) {
         advance_loader();
-        char* base = lds + (ld_step % 3) * C::STAGE_BYTES;
+        char* base = lds + (ld_step % SLOTS) * C::STAGE_BYTES;
         const int k0 = ld_kt * BK;
 #pragma unroll
         for (int i = 0; i < C::A_CHUNKS; ++i)
@@ -496,15 +497,15 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
         for (int kt = 0; kt < KT; ++kt, ++step) {
             // batch `step` has landed; exactly one younger batch stays in flight across the barrier. Epilogue stores
             // issued since only make this wait more conservative (vmcnt completes in order).
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::PER_STAGE) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::PER_STAGE * (AHEAD - 1)) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             advance_loader();
-            // ---- one straight-line block: LDS fragment reads, 32 MFMAs, and the 6 DMA pieces of batch step+2 (into the
+            // ---- one straight-line block: LDS fragment reads, 32 MFMAs, and the DMA pieces of batch step+AHEAD (into the
             // slot read at step-1, free since the barrier) spread BETWEEN the MFMAs. Issued in a burst right after the
             // barrier they cost each wave ~1k cycles of VMEM issue stall while both waves of a SIMD sit idle.
-            const char* base = lds + (step % 3) * C::STAGE_BYTES;
-            char* lbase = lds + (ld_step % 3) * C::STAGE_BYTES;
+            const char* base = lds + (step % SLOTS) * C::STAGE_BYTES;
+            char* lbase = lds + (ld_step % SLOTS) * C::STAGE_BYTES;
             const int k0 = ld_kt * BK;
             half8 af0[MT], wf0[NT], af1[MT], wf1[NT];
 #pragma unroll
@@ -520,6 +521,7 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
                 for (int nt = 0; nt < NT; ++nt) acc[grp][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[nt], af0[grp], acc[grp][nt], 0, 0, 0);
                 af1[grp] = *(const half8*)(base + a_off + grp * 16 * 128 + sw1);
                 wf1[grp] = *(const half8*)(base + w_off + grp * 16 * 128 + sw1);
+                if (NT == 8) wf1[4 + grp] = *(const half8*)(base + w_off + (4 + grp) * 16 * 128 + sw1);
                 __builtin_amdgcn_global_load_lds(MDR_GPTR(a_src[grp] + k0), MDR_LPTR(lbase + (grp * C::THREADS + wave * 64) * 16), 16, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -808,22 +810,22 @@ int launch_gemm_cfg(const _Float16* A, int lda, const _Float16* W, const float* 
     return MDR_OK;
 }
 
-template <int EPI>
+template <int EPI, typename C>
 int launch_gemm_persist(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
                         int num_cus, hipStream_t st) {
-    constexpr int lds = GemmP::LDS_BYTES + kPersistBiasMax * 4;
+    constexpr int lds = C::LDS_BYTES + kPersistBiasMax * 4;
     static bool attr = false;
     if (!attr) {
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI, C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    // XCD grid: split n over gn XCDs until the W slice an L2 must keep (N*K*2/gn bytes) is <= 2.5 MiB; gn must divide 8
+    // XCD grid: split n over gn (a divisor of 8) XCD columns until the W slice an L2 must keep (N*K*2/gn bytes) is <= 2.5 MiB
     static int force_gn = getenv("MDR_GEMM_GN") ? atoi(getenv("MDR_GEMM_GN")) : 0;
     int gn = 1;
-    while (gn < 8 && ((size_t)N * K * 2 / gn > (size_t)(5 << 19) || (N / GemmP::BN) % (gn) != 0)) gn *= 2;
+    while (gn < 8 && (size_t)N * K * 2 / gn > (size_t)(5 << 19) && gn * 2 <= N / C::BN) gn *= 2;  // uneven n splits are fine
     if (force_gn == 1 || force_gn == 2 || force_gn == 4 || force_gn == 8) gn = force_gn;
     const int grid = num_cus / 8 * 8;
-    hipLaunchKernelGGL((gemm_persist_kernel<EPI>), dim3(grid), dim3(GemmP::THREADS), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, gn);
+    hipLaunchKernelGGL((gemm_persist_kernel<EPI, C>), dim3(grid), dim3(C::THREADS), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, gn);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }
@@ -839,7 +841,7 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
     if ((sel == 4 || (sel == 0 && p_tiles >= (long long)num_cus * 3 / 2)) && N % 128 == 0 && N <= kPersistBiasMax) {
         if (res_added) *res_added = false;
         constexpr int E = EPI == EPI_BIAS_RES_F32 ? EPI_BIAS_F32 : EPI;
-        return launch_gemm_persist<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, num_cus, st);
+        return launch_gemm_persist<E, GemmP>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, num_cus, st);
     }
     const long long big_blocks = (N % 256 == 0) ? (long long)(N / 256) * ((M_est + 255) / 256) : 0;
     const long long mid_blocks = (long long)(N / 128) * ((M_est + 127) / 128);
