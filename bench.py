@@ -10,8 +10,14 @@ step    : one batch of 100 questions through hop-1 encode -> MIPS -> hop-2 encod
 N > 1   : launched by torch.distributed.run, one rank per GPU; the corpus is row-sharded, questions are
           split across ranks for the encoder, per-shard top-k lists are exchanged with one RCCL
           all_gather per hop (strong scaling of the fixed 5M-row index).
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = MIPS stream kernel, HBM-bound) and
-`cpu_baseline` (oracle/flat_ip_oracle.c, the FAISS-equivalent CPU path, on a bounded row sample).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the MIPS screen kernel mips_screen_kernel<24,1,0>,
+HBM-bound; time = HIP events around every search call on the launch stream) and `cpu_baseline`
+(oracle/flat_ip_oracle.c, the FAISS-equivalent CPU path, on a bounded row sample).
+
+roofline.traffic is HBM bytes per search call from a separate `rocprofv3 --pmc FETCH_SIZE` pass (scripts/gpu_pmc_screen.sh;
+KB x 1024 x 2, the gfx950 correction of MI355X_MICROARCH.md), which cannot run inside this process: the measured ratio
+traffic / algorithmic bytes of each kernel (table below, source files under profiles/) is applied to this run's
+algorithmic bytes, or pass --pmc-traffic with a fresh measurement.
 """
 import argparse
 import json
@@ -27,6 +33,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CHUNK_ROWS = 250_000
+
+# measured HBM fetch bytes per search call / algorithmic bytes (N_pad * d * 4), from rocprofv3 --pmc FETCH_SIZE passes
+PMC_TRAFFIC_RATIO = {
+    # main 3.75166e6 KB + refine 28996 KB + sample 25367 KB, x2 -> 7.79e9 B at 5M x 768 (15.36e9 B algorithmic)
+    "mips_screen_kernel": (0.5072, "profiles/r01_final_mips5m_pmc_screen_FETCH_SIZE.csv"),
+    "mips_stream_kernel": (1.001, "profiles/r01_mips1m_pmc_fetch_size.csv"),
+}
 
 
 def parse():
@@ -148,8 +161,13 @@ def main():
     search_ms = pipe.search_kernel_ms()  # HIP-event average over every timed search call (rank-local)
     stream_bytes = local.stream_bytes()
     achieved = stream_bytes / (search_ms * 1e-3) / 1e9 if search_ms > 0 else 0.0
+    traffic, traffic_src = args.pmc_traffic, "--pmc-traffic"
+    if traffic is None:
+        for name, (ratio, src) in PMC_TRAFFIC_RATIO.items():
+            if name in local.last_kernel() and d == 768:
+                traffic, traffic_src = float(round(stream_bytes * ratio)), f"{src} (measured ratio {ratio} x algorithmic bytes)"
     roofline = {"bound": "hbm", "kernel": local.last_kernel(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.pmc_traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
                 "algorithmic_bytes_per_launch": stream_bytes,
                 "designed_hbm_bytes_per_launch": stream_bytes // 2 if "screen" in local.last_kernel() else stream_bytes, "avg_launch_ms": round(search_ms, 4),
                 "launches_timed": pipe.search_calls_timed()}
