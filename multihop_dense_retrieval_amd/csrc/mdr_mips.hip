@@ -170,6 +170,15 @@ __global__ void __launch_bounds__(256) query_bound_kernel(const float* __restric
     if (lane == 0) bound[i] = i < nq ? c * sqrtf(s) * sqrtf(__int_as_float(flags[2])) * 1.0001f + 1e-4f : 0.f;
 }
 
+__device__ inline int block_sum_256(int v, int* red) {
+    // red: LDS int[4]
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
 // ---- wave-level candidate list maintenance -----------------------------------------------------------
 __device__ inline u64 load_key_l2(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -177,6 +186,9 @@ __device__ inline u64 load_key_l2(const u64* p) { return __hip_atomic_load(p, __
 // with identical arguments. Returns the k-th largest key (0 if c < k). E*64 >= c.
 template <int E>
 __device__ inline u64 wave_select_topk(u64* list, int c, int k, int lane, int* new_count) {
+    // (before any load: a load left pending on an early return would make the compiler guard every later VMEM op
+    //  of the caller's loop with vmcnt(0) and drain the corpus DMA each stage)
+    if (c < k) { *new_count = c; return 0ull; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's appends have reached L2
     u64 key[E];
 #pragma unroll
@@ -184,7 +196,6 @@ __device__ inline u64 wave_select_topk(u64* list, int c, int k, int lane, int* n
         int idx = e * 64 + lane;
         key[e] = idx < c ? load_key_l2(list + idx) : 0ull;
     }
-    if (c < k) { *new_count = c; return 0ull; }
     u64 t = 0ull;
     for (int bit = 63; bit >= 0; --bit) {
         u64 cand = t | (1ull << bit);
@@ -405,6 +416,7 @@ __device__ __forceinline__ unsigned load_u32_l2(const unsigned* p) { return __hi
 
 constexpr int kWaveCandCap = 2048;  // (query,row) candidates one wave may emit per pass before the exact fallback
 constexpr int kSampleStages = 4;    // super-blocks per workgroup the sample pass scores (x 256 workgroups x 32 rows)
+constexpr int kSampleStagesK = 16;  // same for the k > 1 sample pass (MODE 2): 131k rows, spread over each workgroup's range
 
 // MODE 0 (sample pass): score the first kSampleStages super-blocks of every workgroup, emit nothing, publish
 //         the largest s_hi per query to gmax. The kernel boundary is the grid-wide synchronisation.
@@ -431,9 +443,12 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
     const int G = gridDim.x, b = blockIdx.x;
     int n_it = (n_sb - b + G - 1) / G;  // >= 1 (grid <= n_sb)
     if (MODE == 0 && n_it > kSampleStages) n_it = kSampleStages;
+    int step_ = 1;  // MODE 2 spreads its sample stages over the workgroup's whole row range
+    if (MODE == 2 && n_it > kSampleStagesK) { step_ = n_it / kSampleStagesK; n_it = kSampleStagesK; }
+    const int sG = (MODE == 2 ? step_ : 1) * G;  // super-block stride between consecutive stages
 
     issue_super_block<NKB>(Xhi, b, lds, wave, lane);
-    if (n_it > 1) issue_super_block<NKB>(Xhi, b + G, lds + SB_BYTES, wave, lane);
+    if (n_it > 1) issue_super_block<NKB>(Xhi, b + sG, lds + SB_BYTES, wave, lane);
 
     const bool wave_active = wave * 16 < nq;
     half8 qh[NKB];
@@ -483,7 +498,7 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
             }
             known = __shfl(kn, lane & 15);
         }
-        if (it + 2 < n_it) issue_super_block<NKB>(Xhi, b + (it + 2) * G, lds + ((it + 2) % 3) * SB_BYTES, wave, lane);
+        if (it + 2 < n_it) issue_super_block<NKB>(Xhi, b + (it + 2) * sG, lds + ((it + 2) % 3) * SB_BYTES, wave, lane);
         if (!wave_active) continue;
 
         const char* p = lds + (it % 3) * SB_BYTES + lane * 16;
@@ -520,7 +535,7 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         const f32x4 s0 = a00 + a01, s1 = a10 + a11;
-        const unsigned row0 = (unsigned)(b + it * G) * 32u + sub_row;
+        const unsigned row0 = (unsigned)(b + it * sG) * 32u + sub_row;
         const float cut = known - band2;  // a row below this cannot beat the row that produced `known`
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -550,13 +565,44 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
         float hm = fmaxf(hmax, __shfl_xor(hmax, 16));
         hm = fmaxf(hm, __shfl_xor(hm, 32));
         if (lane < 16 && q_valid && hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
+    } else if (MODE == 2) {  // per-workgroup maxima (no atomics): gmax is [G][kStreamQ] here
+        float hm = fmaxf(hmax, __shfl_xor(hmax, 16));
+        hm = fmaxf(hm, __shfl_xor(hm, 32));
+        if (lane < 16 && q_valid) gmax[(size_t)b * kStreamQ + qlocal] = hm > -FLT_MAX ? ord32(hm) : 0u;
     } else if (lane == 0) {
         cand_cnt[b * 8 + wave] = my_cnt < kWaveCandCap ? my_cnt : kWaveCandCap;
         if (my_cnt > kWaveCandCap) *overflow = 1;
     }
 }
 
-// exact re-scoring of the screen kernel's candidates: 16 lanes per (query, row), fp32 FMA on both planes;
+// exact fp32 score of one (query, row) pair by a 16-lane group (sub = lane within the group): FMA over the
+// reconstructed values of both planes, then a 16-lane butterfly. Every lane of the group returns the sum.
+template <bool BF>
+__device__ __forceinline__ float exact_dot16(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ qrow,
+                                             unsigned row, int sub) {
+    const size_t base = ((size_t)(row >> 4) * nkb) * kFragBytes + (size_t)(row & 15) * 16;
+    float acc = 0.f;
+    for (int pc = sub; pc < nkb * 4; pc += 16) {  // piece = (k-block, 8-column group)
+        const int kb = pc >> 2, g = pc & 3;
+        const size_t off = base + (size_t)kb * kFragBytes + (size_t)g * 256;
+        const float* qp = qrow + kb * 32 + g * 8;
+        if (BF) {
+            const ushort8 hb = *(const ushort8*)(Xhi + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(bf16_bits_to_f32(hb[j]), qp[j], acc);
+        } else {
+            const half8 h = *(const half8*)(Xhi + off);
+            const half8 l = *(const half8*)(Xlo + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf((float)h[j] + (float)l[j] * kLoInv, qp[j], acc);
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    return acc;
+}
+
+// exact re-scoring of the screen kernel's candidates: 16 lanes per (query, row);
 // one 256-thread block per source wave list, 16 candidates in flight per block
 template <bool BF>
 __global__ void __launch_bounds__(256)
@@ -570,27 +616,289 @@ mips_refine_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, i
     for (int c = threadIdx.x >> 4; c < n; c += 16) {
         const u64 e = list[c];
         const unsigned qi = (unsigned)(e >> 32), row = (unsigned)e;
-        const size_t base = ((size_t)(row >> 4) * nkb) * kFragBytes + (size_t)(row & 15) * 16;
-        float acc = 0.f;
-        for (int pc = sub; pc < nkb * 4; pc += 16) {  // piece = (k-block, 8-column group)
-            const int kb = pc >> 2, g = pc & 3;
-            const size_t off = base + (size_t)kb * kFragBytes + (size_t)g * 256;
-            const float* qp = q + (size_t)qi * d + kb * 32 + g * 8;
-            if (BF) {
-                const ushort8 hb = *(const ushort8*)(Xhi + off);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc = fmaf(bf16_bits_to_f32(hb[j]), qp[j], acc);
-            } else {
-                const half8 h = *(const half8*)(Xhi + off);
-                const half8 l = *(const half8*)(Xlo + off);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc = fmaf((float)h[j] + (float)l[j] * kLoInv, qp[j], acc);
-            }
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        const float acc = exact_dot16<BF>(Xhi, Xlo, nkb, q + (size_t)qi * d, row, sub);
         if (sub == 0) atomicMax(best + qi, make_key(acc, row));
     }
+}
+
+// ---- the screen kernel for 2 <= k <= 128: hi plane only, per-(workgroup, query) lists keyed by s_hi ---------
+// A row can be among the k best exact scores only if s_hi >= h_k - 2B, h_k = k-th largest s_hi over ALL rows
+// (k rows have exact >= h_k - B, and s_hi < h_k - 2B means exact < h_k - B). Any lower bound on h_k will do:
+//   1. sample pass (mips_screen_kernel MODE 2): every workgroup scores kSampleStagesK super-blocks and publishes its
+//      largest s_hi per query; the k-th largest of those G maxima (k distinct rows!) is the first bound (tau0).
+//   2. main pass: rows with s_hi >= bound - 2B are appended to the (workgroup, query) list; should a list run full it
+//      is pruned to (its own k-th largest) - 2B, which becomes that list's bound. Bounds only rise and never exceed
+//      h_k, so the union of the lists holds every possible winner.
+//   3. merge_screenk_kernel: h_k over the union, keep the band, re-score it exactly (both planes), sort.
+constexpr int kScreenKCap = 512;       // slots per (workgroup, query)
+constexpr int kSurvMax = 1024;         // band survivors per query the merge kernel re-scores before giving up (-> exact fallback)
+constexpr int kMergeKLds = 15360;      // union keys per query the merge kernel holds in LDS (120 KiB) before giving up
+
+__device__ __forceinline__ u64 floor_key(float score) { return (u64)ord32(score) << 32; }  // smallest key with that score
+
+// Whole wave, identical arguments, c >= k. list[0..c): unique keys. Finds t = k-th largest key, keeps the keys with
+// score >= score(t) - band2 compacted to the front. If that band would leave fewer than 32 free slots it keeps only
+// the k best and raises *overflow (the results of this pass are then discarded by the exact fallback). Returns t.
+template <int E>
+__device__ inline u64 wave_select_band(u64* list, int c, int k, float band2, int lane, int* new_count, int* overflow) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's appends have reached L2
+    u64 key[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int idx = e * 64 + lane;
+        key[e] = idx < c ? load_key_l2(list + idx) : 0ull;
+    }
+    u64 t = 0ull;
+    for (int bit = 63; bit >= 0; --bit) {
+        u64 cnd = t | (1ull << bit);
+        int n = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) n += __popcll(__ballot(key[e] >= cnd));
+        if (n >= k) t = cnd;
+    }
+    u64 cut = floor_key(key_score(t) - band2);
+    int n_band = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) n_band += __popcll(__ballot(key[e] >= cut && key[e] != 0ull));
+    if (n_band > E * 64 - 64) {
+        cut = t;
+        if (lane == 0) *overflow = 1;
+    }
+    int base = 0;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        bool p = key[e] >= cut && key[e] != 0ull;
+        u64 m = __ballot(p);
+        if (p) list[base + __popcll(m & lt)] = key[e];
+        base += __popcll(m);
+    }
+    *new_count = base;
+    return t;
+}
+
+// k-th largest of the G per-workgroup sample maxima of each query -> tau0 (-inf when fewer than k workgroups saw a row)
+__global__ void __launch_bounds__(256) kth_of_maxima_kernel(const unsigned* __restrict__ wgmax /* [G][kStreamQ] ordered, 0 = none */, int G, int k,
+                                                            float* __restrict__ tau0 /* [kStreamQ] */) {
+    const int ql = blockIdx.x;
+    __shared__ unsigned v[1024];
+    __shared__ int found;
+    if (threadIdx.x == 0) found = 0;
+    for (int i = threadIdx.x; i < G; i += 256) v[i] = wgmax[(size_t)i * kStreamQ + ql];
+    __syncthreads();
+    for (int i = threadIdx.x; i < G; i += 256) {
+        const unsigned me = v[i];
+        if (me == 0u) continue;
+        int rank = 0;
+        for (int j = 0; j < G; ++j) rank += (v[j] > me) || (v[j] == me && j < i);
+        if (rank == k - 1) { tau0[ql] = unord32(me); found = 1; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && !found) tau0[ql] = -INFINITY;
+}
+
+template <int NKB, bool BF>
+__global__ void __launch_bounds__(512, 2)
+mips_screenk_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, const char* __restrict__ Qhi, const float* __restrict__ qbound,
+                    const float* __restrict__ tau0, int nq, u64* __restrict__ cand /* [G][kStreamQ][kScreenKCap] */, int* __restrict__ cand_cnt, int k,
+                    int* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int SB_BYTES = 2 * NKB * kFragBytes;
+    constexpr int CPW = NKB / 4;
+    constexpr int HK = NKB / 2;
+    constexpr int E = kScreenKCap / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = gridDim.x, b = blockIdx.x;
+    const int n_it = (n_sb - b + G - 1) / G;  // >= 1 (grid <= n_sb)
+
+    issue_super_block<NKB>(Xhi, b, lds, wave, lane);
+    if (n_it > 1) issue_super_block<NKB>(Xhi, b + G, lds + SB_BYTES, wave, lane);
+
+    const bool wave_active = wave * 16 < nq;
+    half8 qh[NKB];
+    {
+        const size_t qoff = (size_t)wave * NKB * kFragBytes + lane * 16;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) qh[kb] = *(const half8*)(Qhi + qoff + kb * kFragBytes);
+    }
+    const int qlocal = wave * 16 + (lane & 15);
+    const bool q_valid = qlocal < nq;
+    float band2 = q_valid ? 2.f * qbound[qlocal] : 0.f;
+    float tau = q_valid ? tau0[qlocal] - band2 : INFINITY;  // rows below this s_hi cannot be among the k best of this lane's query
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(qh[kb]));  // retire the loads before the DMA loop (see mips_stream_kernel)
+    asm volatile("" : "+v"(band2), "+v"(tau));
+    const unsigned sub_row = 4u * (unsigned)(lane >> 4);
+    u64* wave_lists = cand + ((size_t)b * kStreamQ + (size_t)wave * 16) * kScreenKCap;
+    u64* my_list = wave_lists + (size_t)(lane & 15) * kScreenKCap;
+    int cnt = 0;  // entries in this lane's query list; replicated in the 4 lanes (l, l^16, l^32, l^48) that share the query
+    const u64 below_mask = (1ull << (lane & 48)) - 1ull;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;  // scores of the previous stage, consumed one iteration later
+    unsigned prow0 = 0;
+
+    // Appends of stage it-1 are issued at the top of iteration it, BEFORE that iteration's DMA: the stores are then older
+    // than the newest DMA batch and the counted vmcnt wait of the next iteration does not have to cover that batch.
+    // Slots come from a ballot prefix over the 4 lanes of a query: no atomics, no LDS, nothing that waits on vmcnt.
+    auto flush = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sc = j < 4 ? s0[j & 3] : s1[j & 3];
+            const unsigned row = prow0 + 16u * (j >> 2) + (j & 3);
+            const bool hit = q_valid && (long long)row < n_rows && sc >= tau;
+            const u64 m = __ballot(hit);
+            if (m) {  // wave-uniform
+                const u64 grp = (m >> (lane & 15)) & 0x0001000100010001ull;
+                const int slot = cnt + __popcll(grp & below_mask);
+                if (hit && slot < kScreenKCap) my_list[slot] = make_key(sc, row);
+                cnt += __popcll(grp);
+            }
+        }
+        unsigned m16 = (unsigned)(__ballot(cnt > kScreenKCap - 32) & 0xFFFFull);
+        while (m16) {  // rare: a list is about to run full -> prune it to (its k-th largest) - 2B
+            const int qi = __builtin_ctz(m16);
+            m16 &= m16 - 1;
+            int nc;
+            const u64 t = wave_select_band<E>(wave_lists + (size_t)qi * kScreenKCap, __shfl(cnt, qi), k, __shfl(band2, qi), lane, &nc, overflow);
+            if ((lane & 15) == qi) {
+                cnt = nc;
+                tau = fmaxf(tau, key_score(t) - band2);
+            }
+        }
+    };
+
+    for (int it = 0; it < n_it; ++it) {
+        if (it + 1 < n_it)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wave_active && it > 0) flush();
+        if (it + 2 < n_it) issue_super_block<NKB>(Xhi, b + (it + 2) * G, lds + ((it + 2) % 3) * SB_BYTES, wave, lane);
+        if (!wave_active) continue;
+
+        const char* p = lds + (it % 3) * SB_BYTES + lane * 16;
+        f32x4 a00 = {0.f, 0.f, 0.f, 0.f}, a01 = a00, a10 = a00, a11 = a00;
+        constexpr int PF = 2;
+        half8 x00[PF], x01[PF], x10[PF], x11[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            x00[i] = *(const half8*)(p + i * kFragBytes);
+            x01[i] = *(const half8*)(p + (HK + i) * kFragBytes);
+            x10[i] = *(const half8*)(p + (NKB + i) * kFragBytes);
+            x11[i] = *(const half8*)(p + (NKB + HK + i) * kFragBytes);
+        }
+#pragma unroll
+        for (int kb = 0; kb < HK; ++kb) {
+            const half8 c00 = x00[kb % PF], c01 = x01[kb % PF], c10 = x10[kb % PF], c11 = x11[kb % PF];
+            if (kb + PF < HK) {
+                x00[kb % PF] = *(const half8*)(p + (kb + PF) * kFragBytes);
+                x01[kb % PF] = *(const half8*)(p + (HK + kb + PF) * kFragBytes);
+                x10[kb % PF] = *(const half8*)(p + (NKB + kb + PF) * kFragBytes);
+                x11[kb % PF] = *(const half8*)(p + (NKB + HK + kb + PF) * kFragBytes);
+            }
+            a00 = mfma16<BF>(c00, qh[kb], a00);
+            a01 = mfma16<BF>(c01, qh[HK + kb], a01);
+            a10 = mfma16<BF>(c10, qh[kb], a10);
+            a11 = mfma16<BF>(c11, qh[HK + kb], a11);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * PF, 0);
+#pragma unroll
+        for (int kb = 0; kb < HK; ++kb) {
+            if (kb + PF < HK) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        s0 = a00 + a01;
+        s1 = a10 + a11;
+        prow0 = (unsigned)(b + it * G) * 32u + sub_row;
+    }
+    if (wave_active) {
+        flush();
+        if (lane < 16) cand_cnt[(size_t)b * kStreamQ + qlocal] = cnt;
+    }
+}
+
+// One 256-thread block per query: union of the G lists -> h_k (k-th largest s_hi) -> band survivors -> exact scores
+// (16 lanes per survivor, both planes) -> the k best by (exact score desc, id asc). Raises *overflow (and returns;
+// the exact fallback pass then rewrites D/I) when the union or the band does not fit.
+template <bool BF>
+__global__ void __launch_bounds__(256)
+merge_screenk_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_cnt, int G, int k, const float* __restrict__ qbound,
+                     const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, float* __restrict__ D,
+                     long long* __restrict__ I, long long id_offset, int* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    u64* keys = (u64*)lds;  // [kMergeKLds]
+    __shared__ u64 surv[kSurvMax];
+    __shared__ int red[4];
+    __shared__ int s_n;
+    const int ql = blockIdx.x;
+    const int tid = threadIdx.x;
+    float* Dq = D + (size_t)ql * k;
+    long long* Iq = I + (size_t)ql * k;
+    const float band2 = 2.f * qbound[ql];
+
+    int total = 0;
+    for (int w = tid; w < G; w += 256) total += cand_cnt[(size_t)w * kStreamQ + ql];
+    total = block_sum_256(total, red);
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int kk = total < k ? total : k;
+    if (kk == 0) {
+        for (int i = tid; i < k; i += 256) { Dq[i] = -FLT_MAX; Iq[i] = -1; }
+        return;
+    }
+    if (total > kMergeKLds) {
+        if (tid == 0) *overflow = 1;
+        return;
+    }
+    for (int w = 0; w < G; ++w) {
+        const int c = cand_cnt[(size_t)w * kStreamQ + ql];
+        const u64* lst = cand + ((size_t)w * kStreamQ + ql) * kScreenKCap;
+        for (int i = tid; i < c; i += 256) keys[atomicAdd(&s_n, 1)] = lst[i];
+    }
+    __syncthreads();
+    const int S = s_n;  // == total
+    u64 hk = 0ull;      // kk-th largest s_hi key of the union
+    for (int bit = 63; bit >= 0; --bit) {
+        const u64 c = hk | (1ull << bit);
+        int n = 0;
+        for (int i = tid; i < S; i += 256) n += keys[i] >= c;
+        n = block_sum_256(n, red);
+        if (n >= kk) hk = c;
+    }
+    const u64 cut = total < k ? 0ull : floor_key(key_score(hk) - band2);
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int i = tid; i < S; i += 256)
+        if (keys[i] >= cut) {
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < kSurvMax) surv[pos] = keys[i];
+        }
+    __syncthreads();
+    const int ns = s_n;
+    if (ns > kSurvMax) {
+        if (tid == 0) *overflow = 1;
+        return;
+    }
+    const int sub = tid & 15;
+    const float* qrow = q + (size_t)ql * (nkb * 32);
+    for (int c = tid >> 4; c < ns; c += 16) {
+        const unsigned row = key_row(surv[c]);
+        const float acc = exact_dot16<BF>(Xhi, Xlo, nkb, qrow, row, sub);
+        if (sub == 0) surv[c] = make_key(acc, row);  // only this 16-lane group touches surv[c]
+    }
+    __syncthreads();
+    for (int i = tid; i < ns; i += 256) {
+        const u64 me = surv[i];
+        int rank = 0;
+        for (int j = 0; j < ns; ++j) rank += surv[j] > me;
+        if (rank < kk) {
+            Dq[rank] = key_score(me);
+            Iq[rank] = id_offset + (long long)key_row(me);
+        }
+    }
+    for (int i = kk + tid; i < k; i += 256) { Dq[i] = -FLT_MAX; Iq[i] = -1; }
 }
 
 // ---- generic kernel: any d (multiple of 32), fp32 FMA on the reconstructed values ------------------
@@ -669,15 +977,6 @@ __global__ void finalize_top1_kernel(const u64* __restrict__ best, int nq, float
     unsigned row = key_row(key);
     if (key == 0ull || row == 0xFFFFFFFFu) { D[q] = -FLT_MAX; I[q] = -1; }
     else { D[q] = key_score(key); I[q] = id_offset + (long long)row; }
-}
-
-__device__ inline int block_sum_256(int v, int* red) {
-    // red: LDS int[4]
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
 }
 
 // general k: merge G per-workgroup lists of one query group. One 256-thread block per query.
@@ -899,13 +1198,14 @@ size_t elem_size(int dtype) { return dtype == MDR_DT_F32 ? 4 : 2; }
 
 bool is_bf16(const mdr_index* h) { return h->storage == MDR_STORE_BF16; }
 bool stream_kernel_supports(const mdr_index* h, int k) { return !is_bf16(h) && h->d == 768 && k <= 128; }
-bool screen_kernel_supports(const mdr_index* h, int k) { return h->d == 768 && k == 1; }
+bool screen_kernel_supports(const mdr_index* h, int k) { return h->d == 768 && k <= 128; }
 
 enum Path { PATH_GENERIC = 1, PATH_STREAM = 2, PATH_SCREEN = 3 };
 
 struct SearchPlan {
     int path;
     int G;    // workgroups of the stream / screen kernels
+    int Gx;   // workgroups of the exact stream kernel (== G on the stream path; the fallback behind the screen kernels)
     int Gg;   // workgroups of the generic kernel (when its lists are needed)
     bool lists_stream, lists_generic;
     size_t off_qhi, off_qlo, off_bound, off_best, off_gmax, off_scand, off_sctl, off_cand, off_cnt, off_kth, total;
@@ -922,11 +1222,14 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     const long long n_rb = (h->ntotal + 15) / 16;
     const long long units = p.path == PATH_SCREEN ? (h->ntotal + 31) / 32 : n_rb;
     p.G = (int)(units < h->num_cus ? (units > 0 ? units : 1) : h->num_cus);
+    if (p.G > 1024) p.G = 1024;  // kth_of_maxima_kernel holds one value per workgroup in LDS
+    p.Gx = (int)(n_rb < h->num_cus ? (n_rb > 0 ? n_rb : 1) : h->num_cus);
     const long long gg = (long long)h->num_cus * 2;
     p.Gg = (int)(n_rb < gg ? (n_rb > 0 ? n_rb : 1) : gg);
     // which candidate-list workspaces this call can touch (incl. the conditional exact pass behind the screen kernel)
-    p.lists_stream = p.path == PATH_STREAM && k > 1;
+    p.lists_stream = (p.path == PATH_STREAM || (p.path == PATH_SCREEN && !is_bf16(h))) && k > 1;
     p.lists_generic = p.path == PATH_GENERIC || (p.path == PATH_SCREEN && is_bf16(h));
+    const bool screenk = p.path == PATH_SCREEN && k > 1;
     const bool frag = p.path != PATH_GENERIC;
     const size_t nq_pad = (size_t)((nq + kStreamQ - 1) / kStreamQ) * kStreamQ;
     size_t o = 0;
@@ -936,10 +1239,17 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     p.off_bound = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
     p.off_best = take((size_t)(nq > 0 ? nq : 1) * 8);
     p.off_gmax = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
-    p.off_scand = take(p.path == PATH_SCREEN ? (size_t)p.G * 8 * kWaveCandCap * 8 : 0);  // one private list per wave
+    // k == 1: one private list per wave; k > 1: the [G][kStreamQ] sample maxima
+    p.off_scand = take(p.path != PATH_SCREEN ? 0 : (k == 1 ? (size_t)p.G * 8 * kWaveCandCap * 8 : (size_t)p.G * kStreamQ * 4));
     p.off_sctl = take(p.path == PATH_SCREEN ? 256 + (size_t)p.G * 8 * 4 : 0);            // [0] overflow flag, [64..] per-wave counts
-    const size_t lists = p.lists_stream ? (size_t)p.G * kStreamQ * kStreamCap : (p.lists_generic ? (size_t)p.Gg * kGenericQ * kGenericCap : 0);
-    const size_t slots = p.lists_stream ? (size_t)p.G * kStreamQ : (p.lists_generic ? (size_t)p.Gg * kGenericQ : 0);
+    // the screen-k lists and the lists of its conditional exact pass (which runs after them in stream order) share one region
+    size_t lists = p.lists_stream ? (size_t)p.Gx * kStreamQ * kStreamCap : (p.lists_generic ? (size_t)p.Gg * kGenericQ * kGenericCap : 0);
+    size_t slots = p.lists_stream ? (size_t)p.Gx * kStreamQ : (p.lists_generic ? (size_t)p.Gg * kGenericQ : 0);
+    if (screenk) {
+        const size_t l2 = (size_t)p.G * kStreamQ * kScreenKCap, s2 = (size_t)p.G * kStreamQ;
+        lists = lists > l2 ? lists : l2;
+        slots = slots > s2 ? slots : s2;
+    }
     p.off_cand = take(lists * 8);
     p.off_cnt = take(slots * 4);
     p.off_kth = take(slots * 8);
@@ -1002,6 +1312,53 @@ int run_screen(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, 
                            (const float*)(bound + (size_t)gi * kStreamQ), nqg, gi * kStreamQ, gmax + (size_t)gi * kStreamQ, scand, wave_cnt, sctl);
         hipLaunchKernelGGL((mips_refine_kernel<BF>), dim3(p.G * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
                            (const u64*)scand, (const int*)wave_cnt, best);
+        MDR_HIP_TRY(hipGetLastError());
+    }
+    return MDR_OK;
+}
+
+// 2 <= k <= 128: sample pass -> k-th of the workgroup maxima -> screen-k kernel -> merge/refine, per query group;
+// sctl[0] = overflow flag for the conditional exact pass
+template <bool BF>
+int run_screenk(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, int k, const char* qhi, float* D_dev, long long* I_dev,
+                long long id_offset, hipStream_t st) {
+    constexpr int NKB = 24;
+    const size_t lds_bytes = 3 * (size_t)NKB * 2 * kFragBytes;
+    const size_t merge_lds = (size_t)kMergeKLds * 8;
+    static bool attr = false;
+    if (!attr) {
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screen_kernel<NKB, 2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screenk_kernel<NKB, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)merge_screenk_kernel<BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_lds));
+        attr = true;
+    }
+    float* bound = (float*)(ws + p.off_bound);
+    float* tau0 = (float*)(ws + p.off_gmax);
+    unsigned* wgmax = (unsigned*)(ws + p.off_scand);
+    int* sctl = (int*)(ws + p.off_sctl);
+    u64* cand = (u64*)(ws + p.off_cand);
+    int* cnt = (int*)(ws + p.off_cnt);
+    const int ngroups = (nq + kStreamQ - 1) / kStreamQ;
+    const int nq_pad = ngroups * kStreamQ;
+    const int n_sb = (int)((h->ntotal + 31) / 32);
+    const size_t qgroup_bytes = (size_t)kStreamQ * h->d * 2;
+    const float c = BF ? 2.2e-3f : 1.2e-3f;  // see run_screen
+    MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
+    hipLaunchKernelGGL(query_bound_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)h->flags, c, bound);
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int nqg = nq - gi * kStreamQ < kStreamQ ? nq - gi * kStreamQ : kStreamQ;
+        const char* qg = qhi + gi * qgroup_bytes;
+        const float* bg = bound + (size_t)gi * kStreamQ;
+        float* tg = tau0 + (size_t)gi * kStreamQ;
+        MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * kStreamQ * 4, st));
+        hipLaunchKernelGGL((mips_screen_kernel<NKB, 2, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg, nqg,
+                           gi * kStreamQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr);
+        hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G, k, tg);
+        hipLaunchKernelGGL((mips_screenk_kernel<NKB, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg,
+                           (const float*)tg, nqg, cand, cnt, k, sctl);
+        hipLaunchKernelGGL((merge_screenk_kernel<BF>), dim3(nqg), dim3(256), merge_lds, st, (const u64*)cand, (const int*)cnt, p.G, k, bg, (const char*)h->hi,
+                           (const char*)h->lo, h->nkb, q_dev + (size_t)gi * kStreamQ * h->d, D_dev + (size_t)gi * kStreamQ * k,
+                           I_dev + (size_t)gi * kStreamQ * k, id_offset, sctl);
         MDR_HIP_TRY(hipGetLastError());
     }
     return MDR_OK;
@@ -1133,7 +1490,7 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
     if (h->variant == PATH_STREAM && !stream_kernel_supports(h, k))
         return set_error(MDR_E_INVALID, "stream kernel forced but unsupported for d=%d k=%d storage=%d (needs F32X2H, d=768, k<=128)", h->d, k, h->storage);
     if (h->variant == PATH_SCREEN && !screen_kernel_supports(h, k))
-        return set_error(MDR_E_INVALID, "screen kernel forced but unsupported for d=%d k=%d (needs d=768, k=1)", h->d, k);
+        return set_error(MDR_E_INVALID, "screen kernel forced but unsupported for d=%d k=%d (needs d=768, k<=128)", h->d, k);
     DeviceGuard g(h->device);
     hipStream_t st = (hipStream_t)stream;
     long long* I_ll = (long long*)I_dev;
@@ -1201,7 +1558,19 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
         return MDR_OK;
     }
 
-    // 2 <= k <= 128, F32X2H: exact stream kernel with candidate lists
+    // 2 <= k <= 128
+    const int* run_if = nullptr;
+    if (p.path == PATH_SCREEN) {
+        rc = bf ? run_screenk<true>(h, p, ws, q_dev, nq, k, qhi, D_dev, I_ll, id_offset, st)
+                : run_screenk<false>(h, p, ws, q_dev, nq, k, qhi, D_dev, I_ll, id_offset, st);
+        if (rc) return rc;
+        run_if = (const int*)(ws + p.off_sctl);  // exact pass below: only if a list or the band overflowed
+        h->last_kernel = bf ? "mips_screenk_kernel<24,bf16>" : "mips_screenk_kernel<24>";
+        if (bf) return run_generic<true>(h, p, ws, q_dev, nq, k, D_dev, I_ll, id_offset, run_if, st);
+    } else {
+        h->last_kernel = "mips_stream_kernel<24,1>";
+    }
+    // F32X2H: exact stream kernel with candidate lists (unconditional on the stream path)
     u64* cand = (u64*)(ws + p.off_cand);
     int* cnt = (int*)(ws + p.off_cnt);
     u64* kth = (u64*)(ws + p.off_kth);
@@ -1212,17 +1581,16 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
     }
     for (int gi = 0; gi < ngroups; ++gi) {
         const int nqg = nq - gi * kStreamQ < kStreamQ ? nq - gi * kStreamQ : kStreamQ;
-        MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * kStreamQ * 4, st));
-        MDR_HIP_TRY(hipMemsetAsync(kth, 0, (size_t)p.G * kStreamQ * 8, st));
-        hipLaunchKernelGGL((mips_stream_kernel<NKB, 1>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (const char*)h->lo, (long long)h->ntotal,
+        MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.Gx * kStreamQ * 4, st));
+        MDR_HIP_TRY(hipMemsetAsync(kth, 0, (size_t)p.Gx * kStreamQ * 8, st));
+        hipLaunchKernelGGL((mips_stream_kernel<NKB, 1>), dim3(p.Gx), dim3(512), lds_bytes, st, (const char*)h->hi, (const char*)h->lo, (long long)h->ntotal,
                            n_rb, (const char*)(qhi + gi * qgroup_bytes), (const char*)(qlo + gi * qgroup_bytes), nqg, (u64*)nullptr, cand, cnt, kth, k,
-                           (const int*)nullptr);
+                           run_if);
         MDR_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.G, kStreamQ, kStreamCap, k,
-                           D_dev + (size_t)gi * kStreamQ * k, I_ll + (size_t)gi * kStreamQ * k, (long long)id_offset, (const int*)nullptr);
+        hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.Gx, kStreamQ, kStreamCap, k,
+                           D_dev + (size_t)gi * kStreamQ * k, I_ll + (size_t)gi * kStreamQ * k, (long long)id_offset, run_if);
         MDR_HIP_TRY(hipGetLastError());
     }
-    h->last_kernel = "mips_stream_kernel<24,1>";
     return MDR_OK;
 }
 

@@ -128,13 +128,18 @@ class SyntheticTwoHop:
     VOCAB = 50265
 
     def __init__(self, index, batch, beam, topk, dim, device, max_q_len=70, max_q_sp_len=350, use_encoder=True,
-                 planted_rows=None, rank=0, world=1):
+                 planted_rows=None, rank=0, world=1, weak=False):
+        """`weak=False`: ONE batch of `batch` questions shared by all ranks (strong scaling: the encoder work is split).
+        `weak=True`: every rank owns its own batch of `batch` questions (global batch = batch * world): it encodes them,
+        the embeddings of all ranks are all-gathered, every rank searches ALL of them in its row shard, the per-shard
+        lists are all-gathered and merged, and the rank continues with the rows of its own questions."""
         self.index, self.B, self.beam, self.topk, self.d, self.device = index, batch, beam, topk, dim, device
         self.Lq, self.Lsp = max_q_len, max_q_sp_len
         self.use_encoder = use_encoder
         self.rank, self.world = rank, world
+        self.weak = bool(weak) and world > 1
         self.local = getattr(index, "local", index)
-        g = torch.Generator(device=device).manual_seed(2)
+        g = torch.Generator(device=device).manual_seed(2 + (1000 * rank if self.weak else 0))
         B = batch
         self.q_len = torch.randint(8, 41, (B,), generator=g, device=device)
         self.q_ids = torch.randint(3, self.VOCAB, (B, self.Lq), generator=g, device=device)
@@ -161,7 +166,15 @@ class SyntheticTwoHop:
         """`<s> q </s></s> passage </s>` with longest-first truncation to max_q_sp_len (mdr_assemble_hop2)."""
         return self.arena.assemble_hop2(self.q_ids, self.q_mask, I, D, self.Lsp)
 
+    def _own(self, t):
+        """Rows of this rank's own questions out of a [world * n, ...] gathered tensor."""
+        n = t.shape[0] // self.world
+        return t[self.rank * n:(self.rank + 1) * n]
+
     def _encode(self, ids, mask):
+        if self.weak:
+            from .index import all_gather_dim0
+            return all_gather_dim0(self.encoder.encode_q(ids, mask, None), self.world)
         if self.world > 1:
             # data-parallel encoder: each rank encodes a contiguous slice, embeddings are all-gathered
             n = ids.shape[0]
@@ -195,8 +208,13 @@ class SyntheticTwoHop:
             q = self._encode(self.q_ids, self.q_mask)
         else:
             q = self.planted_rows + self.noise
+            if self.weak:
+                from .index import all_gather_dim0
+                q = all_gather_dim0(q, self.world)
         ev.append(self._mark())
         D, I = self._search(q, self.beam)
+        if self.weak:  # continue with this rank's own questions
+            q, D, I = self._own(q), self._own(D).contiguous(), self._own(I).contiguous()
         ev.append(self._mark())
         if self.use_encoder:
             ids, mask = self._hop2_inputs(I, D)
@@ -205,8 +223,13 @@ class SyntheticTwoHop:
         else:
             ev.append(self._mark())
             q2 = (0.5 * q).repeat_interleave(self.beam, 0) + self.table[(I.reshape(-1) % 1024)]
+            if self.weak:
+                from .index import all_gather_dim0
+                q2 = all_gather_dim0(q2.contiguous(), self.world)
         ev.append(self._mark())
         D2, I2 = self._search(q2.contiguous(), self.beam)
+        if self.weak:
+            D2, I2 = self._own(D2).contiguous(), self._own(I2).contiguous()
         ev.append(self._mark())
         h1, h2, s = rank_paths_device(D, I, D2, I2, self.beam, self.topk)
         ev.append(self._mark())
