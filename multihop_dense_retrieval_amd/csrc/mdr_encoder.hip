@@ -563,6 +563,247 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus batches must have landed before the LDS is released
 }
 
+
+// ---- ping-pong GEMM for large M: 256x256x64 tiles, two wave groups half a phase apart ---------------------
+// The 8 waves form 2 (m) x 4 (n) with a 128x64 output each; waves w and w+4 share a SIMD and belong to different
+// groups (wr = w >> 2). A K-tile is consumed in 4 phases, one 64x32 quadrant of the wave tile each (16 MFMAs); every
+// phase is a LOAD segment (LDS fragment reads for its quadrant + 2 DMA pieces of a half-tile two K-tiles ahead) and an
+// MFMA segment, each closed by a workgroup barrier. Group 1 executes one extra barrier up front, so while one wave of
+// a SIMD runs its 16 MFMAs the other one does its LDS reads / DMA issue: the matrix pipe always has a wave on it and
+// the loads never sit in front of MFMAs of the same wave (the one-phase-for-all kernel above idles the pipe whenever
+// both waves of a SIMD read LDS at the same time).
+// LDS: 2 slots x [A0 A1 B0 B1] half-tiles of 128 rows x 64 k (16 KiB each, rows XOR-swizzled in the DMA source
+// address). Wave group wr reads only A-half wr; waves wc read B-half wc >> 1.
+// Tick algebra (tick = barrier interval; group 0 runs L_p(T) at tick 8T+2p, M_p(T) at 8T+2p+1, group 1 one later):
+//   reads:  L_0 A-sub0 + B-sub0, L_1 B-sub1, L_2 A-sub1, L_3 none (B-sub0 stays in registers for quadrant (1,0))
+//   DMA  :  L_3(T) B0(T+2), L_0(T+1) B1(T+2), L_1(T+1) A0(T+2), L_2(T+1) A1(T+2)  -- every region is re-filled >= 2
+//           ticks after its last reader retired its reads (lgkmcnt(0) at the top of the following M segment)
+//   waits:  end of L_3(T): vmcnt(4) -> this wave's B0,B1,A0 pieces of K-tile T+1 landed; end of M_3(T): vmcnt(2) ->
+//           its A1 pieces too; both precede, by a barrier, the first read of that data by ANY wave.
+// Persistent over (tile, K-tile) like gemm_persist_kernel (same XCD grid); the epilogue of quadrant q is deferred to
+// L_q of the next tile's first K-tile (its accumulators are not touched before M_q), under the other group's MFMAs.
+// Measured (round 1, scripts/gpu_gemm_bench.py, back-to-back launches): a barrier interval costs ~650-850 cycles here
+// against the 256 its 16 MFMAs need -- removing the DMA, the MFMAs or the fragment reads each recovers only 10-20 %, so
+// it is the 8-barriers-per-K-tile skeleton itself. At 20.6k rows (the retrieval loop: 1-4 tiles per workgroup) it
+// loses to gemm_persist_kernel (qkv 121 vs 99 us, ffn2 178 vs 112 us); at 65k rows it wins by 5-11 % because a 256x256
+// tile moves 1/3 fewer L2->LDS bytes per flop. launch_gemm therefore uses it for >= 48k rows only (corpus encoding).
+constexpr int kPPHalf = 128 * 128;        // bytes of one half-tile
+constexpr int kPPSlot = 4 * kPPHalf;      // A0 A1 B0 B1
+constexpr int kPPLds = 2 * kPPSlot;       // 128 KiB
+
+template <int EPI>
+__global__ void __launch_bounds__(512)
+gemm_pp_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M_cap,
+               const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo, int gn) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* lds_bias = (float*)(lds + kPPLds);
+    const int M = M_dev ? min(*M_dev, M_cap) : M_cap;
+    const int ntn = N / 256, ntm = (M + 255) / 256;
+    const int gm = 8 / gn;
+    const int xcd = blockIdx.x & 7, xm = xcd / gn, xn = xcd % gn;
+    const int cm = xm < ntm ? (ntm - xm + gm - 1) / gm : 0, cn = xn < ntn ? (ntn - xn + gn - 1) / gn : 0;
+    const int lb = blockIdx.x >> 3, G = gridDim.x >> 3;
+    const int local_tiles = cm * cn;
+    if (lb >= local_tiles) return;
+    const int n_my = (local_tiles - lb + G - 1) / G;
+    auto tile_origin = [&](int j, int& m0, int& n0) __attribute__((always_inline)) {
+        const int l = lb + j * G;
+        m0 = (xm + (l / cn) * gm) * 256;
+        n0 = (xn + (l % cn) * gn) * 256;
+    };
+    const int KT = K / BK;  // even (launch_gemm checks K % 128 == 0)
+    const int total = n_my * KT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int g = lane >> 4, lr = lane & 15;
+
+    for (int i = tid; i < N; i += 512) lds_bias[i] = bias[i];
+
+    // ---- loader ----
+    const int ld_row = tid >> 3;                         // row of this thread's piece within a 64-row group
+    const int ld_chunk = ((tid & 7) ^ (ld_row & 7)) * 8; // swizzled k-chunk (elements) it fetches
+    unsigned a_off[2][2];  // element offsets of this thread's A pieces (rows clamped to M - 1); 32-bit: A spans < 2^32 elements
+    unsigned w_off = 0;
+    int ld_tile = 0, ld_kt = 0, ld_T = 0;  // K-tile the next half-tile issue belongs to
+    auto set_load_tile = [&](int j) __attribute__((always_inline)) {
+        int m0, n0;
+        tile_origin(j, m0, n0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int ar = m0 + 128 * h + 64 * i + ld_row;
+                ar = ar < M ? ar : M - 1;  // rows past M are computed on a valid row and never stored
+                a_off[h][i] = (unsigned)ar * (unsigned)lda + (unsigned)ld_chunk;
+            }
+        w_off = (unsigned)(n0 + ld_row) * (unsigned)K + (unsigned)ld_chunk;
+    };
+    // region r in issue order: 0 = B0, 1 = B1, 2 = A0, 3 = A1 of K-tile ld_T (slot ld_T & 1)
+    auto issue_half = [&](int r) __attribute__((always_inline)) {
+        char* slot = lds + (ld_T & 1) * kPPSlot;
+        const int k0 = ld_kt * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const _Float16* src = r < 2 ? W + (w_off + (unsigned)((128 * r + 64 * i) * K + k0)) : A + (a_off[r - 2][i] + (unsigned)k0);
+            char* dst = slot + (r < 2 ? (2 + r) : (r - 2)) * kPPHalf + (i * 512 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds(MDR_GPTR(src), MDR_LPTR(dst), 16, 0, 0);
+        }
+    };
+    // move the loader to the next K-tile; past the end of the stream it stays on the last one (surplus pieces land in
+    // free regions and are never read: the DMA count per phase stays constant, so the counted waits stay exact)
+    auto next_ktile = [&]() __attribute__((always_inline)) {
+        ++ld_T;
+        if (ld_T < total) {
+            if (++ld_kt == KT) { ld_kt = 0; ++ld_tile; set_load_tile(ld_tile); }
+        }
+    };
+
+    // ---- reader offsets (bytes within a slot) ----
+    const int a_rd = wr * kPPHalf + lr * 128;
+    const int b_rd = (2 + (wc >> 1)) * kPPHalf + ((wc & 1) * 64 + lr) * 128;
+    const int sw0 = ((0 * 4 + g) ^ (lane & 7)) << 4, sw1 = ((1 * 4 + g) ^ (lane & 7)) << 4;
+
+    f32x4 acc[2][2][4][2];  // [qi][qj][m-frag][n-frag]
+    half8 af[4][2];         // A fragments of the current row-half: [m-frag][k-half]
+    half8 bf[2][2][2];      // W fragments of both column-halves: [qj][n-frag][k-half]
+
+    auto read_a = [&](const char* slot, int qi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            af[mf][0] = *(const half8*)(slot + a_rd + (64 * qi + 16 * mf) * 128 + sw0);
+            af[mf][1] = *(const half8*)(slot + a_rd + (64 * qi + 16 * mf) * 128 + sw1);
+        }
+    };
+    auto read_b = [&](const char* slot, int qj) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+            bf[qj][nf][0] = *(const half8*)(slot + b_rd + (32 * qj + 16 * nf) * 128 + sw0);
+            bf[qj][nf][1] = *(const half8*)(slot + b_rd + (32 * qj + 16 * nf) * 128 + sw1);
+        }
+    };
+    auto mma = [&](int qi, int qj, bool first) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+        if (first) {
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf)
+                    acc[qi][qj][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[qj][nf][0], af[mf][0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf)
+                    acc[qi][qj][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[qj][nf][0], af[mf][0], acc[qi][qj][mf][nf], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+                acc[qi][qj][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[qj][nf][1], af[mf][1], acc[qi][qj][mf][nf], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // epilogue of one quadrant: lane holds C[m = .. + lr][n = .. + 4g + r]
+    auto store_quadrant = [&](int qi, int qj, int m0, int n0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int m = m0 + 128 * wr + 64 * qi + 16 * mf + lr;
+            if (m >= M) continue;
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                const int n = n0 + 64 * wc + 32 * qj + 16 * nf + 4 * g;
+                const f32x4 b4 = *(const f32x4*)(lds_bias + n);
+                f32x4 v = acc[qi][qj][mf][nf] + b4;
+                if (EPI == EPI_BIAS_GELU_F16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                }
+                if (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
+                    half4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
+                    *(half4*)((_Float16*)out + (size_t)m * ldo + n) = o;
+                } else {
+                    *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
+                }
+            }
+        }
+    };
+
+    // ---- prologue: K-tiles 0 and 1 ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bias loads, before any DMA is in flight
+    set_load_tile(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) issue_half(r);
+    next_ktile();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) issue_half(r);
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");  // K-tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier interval behind group 0
+    asm volatile("" ::: "memory");
+
+    int prev_m0 = 0, prev_n0 = 0, kt = 0, tile = 0;
+    bool have_prev = false;
+    // one K-tile; `slot` is compile-time (the stream is walked two K-tiles per loop iteration)
+    auto ktile = [&](const char* slot) __attribute__((always_inline)) {
+        const bool first = kt == 0;
+        const bool flush = first && have_prev;
+        // ---- phase 0: quadrant (0,0)
+        if (flush) store_quadrant(0, 0, prev_m0, prev_n0);
+        read_b(slot, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(slot, 0);
+        issue_half(1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mma(0, 0, first);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 1: quadrant (0,1)
+        if (flush) store_quadrant(0, 1, prev_m0, prev_n0);
+        read_b(slot, 1);
+        issue_half(2);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mma(0, 1, first);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: quadrant (1,1)
+        if (flush) store_quadrant(1, 1, prev_m0, prev_n0);
+        read_a(slot, 1);
+        issue_half(3);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mma(1, 1, first);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3: quadrant (1,0), W fragments of column-half 0 still in registers
+        if (flush) store_quadrant(1, 0, prev_m0, prev_n0);
+        next_ktile();
+        issue_half(0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mma(1, 0, first);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (++kt == KT) {
+            kt = 0;
+            tile_origin(tile, prev_m0, prev_n0);
+            have_prev = true;
+            ++tile;
+        }
+    };
+    for (int T = 0; T < total; T += 2) {
+        ktile(lds);
+        ktile(lds + kPPSlot);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's extra barrier
+    store_quadrant(0, 0, prev_m0, prev_n0);
+    store_quadrant(0, 1, prev_m0, prev_n0);
+    store_quadrant(1, 1, prev_m0, prev_n0);
+    store_quadrant(1, 0, prev_m0, prev_n0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus DMA pieces must have landed before the LDS is released
+}
+
 using GemmBig = GemmCfg<256, 256, 4, 2, 2>;
 using GemmMid = GemmCfg<128, 128, 2, 2, 2>;
 using GemmSmall = GemmCfg<64, 64, 2, 2, 2>;
@@ -830,17 +1071,44 @@ int launch_gemm_persist(const _Float16* A, int lda, const _Float16* W, const flo
     return MDR_OK;
 }
 
+template <int EPI>
+int launch_gemm_pp(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
+                   int num_cus, hipStream_t st) {
+    constexpr int lds = kPPLds + kPersistBiasMax * 4;
+    static bool attr = false;
+    if (!attr) {
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    static int force_gn = getenv("MDR_GEMM_GN") ? atoi(getenv("MDR_GEMM_GN")) : 0;
+    int gn = 1;
+    while (gn < 8 && (size_t)N * K * 2 / gn > (size_t)(5 << 19) && gn * 2 <= N / 256) gn *= 2;
+    if (force_gn == 1 || force_gn == 2 || force_gn == 4 || force_gn == 8) gn = force_gn;
+    const int grid = num_cus / 8 * 8;
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(grid), dim3(512), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, gn);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
 // M_est: expected number of valid rows (the packed token count is only known on the device).
 // *res_added tells the caller whether the residual went into the output (else the following LayerNorm adds it).
 template <int EPI>
 int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
-                const _Float16* res, int ldr, int M_est, int num_cus, hipStream_t st, bool* res_added = nullptr) {
-    static int sel = getenv("MDR_GEMM_CFG") ? atoi(getenv("MDR_GEMM_CFG")) : 0;  // experiment knob: 1 small, 2 mid, 3 big, 4 persistent
+                const _Float16* res, int ldr, int M_est, int num_cus, hipStream_t st, bool* res_added = nullptr, int force = -1) {
+    // experiment knob: 1 small, 2 mid, 3 big tiles; 4 persistent / 5 ping-pong for the large-M calls (the others keep the heuristic)
+    static int env_sel = getenv("MDR_GEMM_CFG") ? atoi(getenv("MDR_GEMM_CFG")) : 0;
+    int sel = force >= 0 ? force : env_sel;
+    if (force < 0 && (sel == 4 || sel == 5) && (long long)(N / 128) * ((M_est + 255) / 256) < (long long)num_cus * 3 / 2) sel = 0;
     if (res_added) *res_added = true;
     const long long p_tiles = (long long)(N / 128) * ((M_est + 255) / 256);
-    if ((sel == 4 || (sel == 0 && p_tiles >= (long long)num_cus * 3 / 2)) && N % 128 == 0 && N <= kPersistBiasMax) {
+    if ((sel == 4 || sel == 5 || (sel == 0 && p_tiles >= (long long)num_cus * 3 / 2)) && N % 128 == 0 && N <= kPersistBiasMax) {
         if (res_added) *res_added = false;
+        else if (EPI == EPI_BIAS_RES_F32) return set_error(MDR_E_STATE, "large-M GEMM with a residual needs the caller to take the residual (res_added)");
         constexpr int E = EPI == EPI_BIAS_RES_F32 ? EPI_BIAS_F32 : EPI;
+        // the 256x256 ping-pong kernel wins once every workgroup walks several tiles (measured: +5..11 % at 65k rows,
+        // -10..-40 % at 20k rows where a workgroup has 1-4 tiles): corpus-encoding batches, not the retrieval loop
+        if ((sel == 5 || (sel == 0 && M_est >= 49152)) && N % 256 == 0 && K % 128 == 0)
+            return launch_gemm_pp<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, num_cus, st);
         return launch_gemm_persist<E, GemmP>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, num_cus, st);
     }
     const long long big_blocks = (N % 256 == 0) ? (long long)(N / 256) * ((M_est + 255) / 256) : 0;
@@ -980,6 +1248,25 @@ int mdr_encoder_create(const mdr_encoder_config* cfg, const mdr_tensor* tensors,
     (void)hipFree(staging);
     *out = h;
     return MDR_OK;
+}
+
+int mdr_test_gemm_f16(const void* A_dev, const void* W_dev, const float* bias_dev, int M, const int* m_dev, int N, int K, void* out_dev, int epilogue,
+                      int kernel, int device, void* stream) {
+    MDR_REQUIRE(A_dev && W_dev && bias_dev && out_dev, "NULL pointer");
+    MDR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "bad GEMM shape M=%d N=%d K=%d (N, K multiples of 64)", M, N, K);
+    MDR_REQUIRE(epilogue == EPI_BIAS_F16 || epilogue == EPI_BIAS_GELU_F16 || epilogue == EPI_BIAS_F32, "epilogue must be 0, 1 or 3");
+    MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 5, "kernel must be 0, 1, 2, 4 or 5");
+    DeviceGuard guard(device);
+    if (!guard.ok) return set_error(MDR_E_HIP, "hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    int ncu = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    const _Float16* A = (const _Float16*)A_dev;
+    const _Float16* W = (const _Float16*)W_dev;
+    hipStream_t st = (hipStream_t)stream;
+    if (epilogue == EPI_BIAS_F16) return launch_gemm<EPI_BIAS_F16>(A, K, W, bias_dev, M, m_dev, N, K, out_dev, N, nullptr, 0, M, ncu, st, nullptr, kernel);
+    if (epilogue == EPI_BIAS_GELU_F16) return launch_gemm<EPI_BIAS_GELU_F16>(A, K, W, bias_dev, M, m_dev, N, K, out_dev, N, nullptr, 0, M, ncu, st, nullptr, kernel);
+    return launch_gemm<EPI_BIAS_F32>(A, K, W, bias_dev, M, m_dev, N, K, out_dev, N, nullptr, 0, M, ncu, st, nullptr, kernel);
 }
 
 int mdr_encoder_free(mdr_encoder* h) {

@@ -28,6 +28,7 @@
 // top-1 lives in two registers per lane; top-k (k <= 128) in per-wave candidate lists with a
 // running threshold. The [nq, N] score matrix is never materialised.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cfloat>
 #include <cstring>

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the encoder GEMM kernels through the mdr_test_gemm_f16 hook (HIP events, 20 launches each).
+usage: python scripts/gpu_gemm_bench.py [M] [kernels...]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multihop_dense_retrieval_amd import _lib  # noqa: E402
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 20611
+kernels = [int(a) for a in sys.argv[2:]] or [4, 5]
+L = _lib.lib()
+g = torch.Generator(device="cuda").manual_seed(0)
+st = torch.cuda.current_stream().cuda_stream
+for name, N, K, epi in (("qkv", 2304, 768, 0), ("out", 768, 768, 3), ("ffn1", 3072, 768, 1), ("ffn2", 768, 3072, 3)):
+    A = torch.randn((M, K), generator=g, device="cuda").half()
+    W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).half()
+    b = torch.randn((N,), generator=g, device="cuda")
+    out = torch.empty((M, N), device="cuda", dtype=torch.float32)  # large enough for every epilogue
+    for kern in kernels:
+        for _ in range(3):
+            _lib.check(L.mdr_test_gemm_f16(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, None, N, K, out.data_ptr(), epi, kern, 0, st))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            L.mdr_test_gemm_f16(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, None, N, K, out.data_ptr(), epi, kern, 0, st)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        print(f"{name:5s} M={M} N={N} K={K} kernel {kern}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)

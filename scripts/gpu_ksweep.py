@@ -17,9 +17,13 @@ idx.reserve(rows)
 g = torch.Generator(device=dev).manual_seed(0)
 for lo in range(0, rows, 250_000):
     idx.add(torch.randn((min(250_000, rows - lo), 768), generator=g, device=dev))
-for nq in (100, 800):
+planted_mode = os.environ.get("SWEEP_PLANTED") == "1"
+probe = torch.randn((800, 768), generator=torch.Generator(device=dev).manual_seed(0), device=dev)  # == rows 0..799 of the corpus
+for nq in (100, 800) if not os.environ.get("SWEEP_NQ") else (int(os.environ["SWEEP_NQ"]),):
     q = torch.randn((nq, 768), generator=g, device=dev)
-    for k in (1, 4, 8, 100):
+    if planted_mode:  # bench-like queries: a corpus row plus 5% noise (one clear winner per query)
+        q = probe[:nq] + 0.05 * q
+    for k in (1, 4, 8, 100) if not os.environ.get("SWEEP_K") else (int(os.environ["SWEEP_K"]),):
         for variant, name in ((3, "screen"), (1 if storage == "bf16" else 2, "exact")):
             if name == "exact" and storage == "bf16" and (rows > 1_000_000 or nq > 100):
                 continue  # generic fp32 kernel: too slow to be worth GPU minutes

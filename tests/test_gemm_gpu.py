@@ -1,0 +1,70 @@
+"""GPU parity tests (-m gpu) for the encoder's GEMM kernels in isolation (mdr_test_gemm_f16): every kernel flavour
+against a float64 matmul of the same fp16 operands. Tolerance: fp32 accumulation of K <= 3072 products of O(1) values
+-> 2e-3 absolute on f32 outputs; f16 outputs add half-precision rounding of the result (2^-11 relative)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _gemm(A, W, bias, epilogue, kernel, m_valid=None):
+    from multihop_dense_retrieval_amd import _lib
+    L = _lib.lib()
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if epilogue == 3 else torch.float16)
+    m_dev = None
+    if m_valid is not None:
+        m_dev = torch.tensor([m_valid], device="cuda", dtype=torch.int32)
+    _lib.check(L.mdr_test_gemm_f16(A.data_ptr(), W.data_ptr(), bias.data_ptr(), M, m_dev.data_ptr() if m_dev is not None else None, N, K,
+                                   out.data_ptr(), epilogue, kernel, 0, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return out
+
+
+def _reference(A, W, bias, epilogue):
+    ref = A.double() @ W.double().T + bias.double()
+    if epilogue == 1:
+        ref = 0.5 * ref * (1.0 + torch.erf(ref / 2 ** 0.5))
+    return ref
+
+
+SHAPES = [  # (M, N, K): encoder shapes incl. ragged M, one tile, many tiles per workgroup
+    (187, 768, 768), (256, 2304, 768), (1000, 3072, 768), (2413, 768, 3072), (20611, 2304, 768), (33000, 768, 768), (9000, 3072, 768),
+    (9000, 768, 3072), (70000, 768, 768),
+]
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2, 4, 5])
+@pytest.mark.parametrize("epilogue", [0, 1, 3])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gemm_matches_fp64(shape, epilogue, kernel):
+    M, N, K = shape
+    if kernel in (1, 2) and M > 10000:
+        pytest.skip("small-tile kernels are not used at this size")
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn((M, K), generator=g, device="cuda").half()
+    W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).half()
+    bias = torch.randn((N,), generator=g, device="cuda")
+    out = _gemm(A, W, bias, epilogue, kernel)
+    ref = _reference(A, W, bias, epilogue)
+    err = (out.double() - ref).abs()
+    tol = 2e-3 if epilogue == 3 else 2e-3 + ref.abs() * 2 ** -10
+    bad = err > tol
+    assert not bool(bad.any()), f"{int(bad.sum())} bad of {M * N}; worst {err.max().item():.3e} at {np.unravel_index(int(err.argmax()), (M, N))}"
+
+
+@pytest.mark.parametrize("kernel", [0, 4, 5])
+def test_gemm_device_side_row_count(kernel):
+    """Rows past *m_dev are neither computed into nor stored (the packed token count lives on the device)."""
+    M, N, K, valid = 5000, 768, 768, 3333
+    g = torch.Generator(device="cuda").manual_seed(1)
+    A = torch.randn((M, K), generator=g, device="cuda").half()
+    W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).half()
+    bias = torch.zeros((N,), device="cuda")
+    out = _gemm(A, W, bias, 3, kernel, m_valid=valid)
+    ref = _reference(A, W, bias, 3)
+    assert (out[:valid].double() - ref[:valid]).abs().max().item() <= 2e-3
+    assert bool(torch.isnan(out[valid:]).all())
