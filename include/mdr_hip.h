@@ -158,7 +158,7 @@ int mdr_assemble_hop2(const int64_t* q_ids_dev, const int64_t* q_mask_dev, int b
  * inside HF RobertaModel's layers (the reference reaches them through model.encode_q, mhop_retriever.py:23-26).
  * A, W: f16 device, K-contiguous; bias f32. epilogue: 0 = bias -> f16 out, 1 = bias + erf-GELU -> f16 out,
  * 3 = bias -> f32 out. kernel: 0 = the shape heuristic the encoder uses, 1 = 64x64 tiles, 2 = 128x128, 4 = persistent
- * 256x128, 5 = ping-pong 256x256 (N % 256 == 0 and K % 128 == 0). m_dev (may be NULL) is a device int holding the
+ * 256x128, 6 = persistent 256x256 (N % 256 == 0). m_dev (may be NULL) is a device int holding the
  * number of valid rows (<= M), as the packed token count is only known on the device.
  * ---------------------------------------------------------------------------------------------- */
 int mdr_test_gemm_f16(const void* A_dev, const void* W_dev, const float* bias_dev, int M, const int* m_dev, int N, int K,

@@ -21,6 +21,7 @@
 //                                       S = QK^T on MFMA, fp32 softmax in registers, O = PV on MFMA
 //   layernorm                           fp32 [T,H] -> fp16 (hidden state) or fp32 (final embedding)
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cmath>
 #include <cstdlib>
@@ -386,6 +387,22 @@ gemm_f16_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
     }
 }
 
+// XCD columns, decided on the device (the packed row count is only known there): among gn = 1, 2, 4, 8 (<= n-tiles) take
+// the one whose busiest XCD walks the fewest rounds of tiles; ties go to gn_rule (the host's L2-capacity choice), then
+// to the smaller gn. Every workgroup evaluates the same expression, so they all agree.
+__device__ inline int pick_gn_device(int ntm, int ntn, int gn_rule, int wgs_per_xcd) {
+    int best = gn_rule, best_r = 0x7fffffff;
+#pragma unroll
+    for (int c = 1; c <= 8; c *= 2) {
+        if (c > ntn && c != 1) continue;
+        const int gm = 8 / c;
+        const int local = ((ntm + gm - 1) / gm) * ((ntn + c - 1) / c);
+        const int r = (local + wgs_per_xcd - 1) / wgs_per_xcd;
+        if (r < best_r || (r == best_r && c == gn_rule)) { best = c; best_r = r; }
+    }
+    return best;
+}
+
 // ---- persistent GEMM for large M ------------------------------------------------------------------------
 // K is short here (768 or 3072): a one-tile-per-block kernel spends as long filling and draining its LDS ring
 // as computing. This kernel keeps ONE 512-thread block per CU alive and walks (tile, k-step) as one flat stream:
@@ -414,6 +431,7 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
     // on ONE L2 at the same time and each L2 only ever holds 1/gn of W. Without it every XCD pulled all of A through the
     // fabric (measured: 8x the algorithmic A traffic, the FFN2 GEMM ran at the fabric's 5.8 TB/s).
     const int ntn = N / C::BN, ntm = (M + C::BM - 1) / C::BM;
+    gn = pick_gn_device(ntm, ntn, gn, gridDim.x >> 3);
     const int gm = 8 / gn;
     const int xcd = blockIdx.x & 7, xm = xcd / gn, xn = xcd % gn;
     const int cm = xm < ntm ? (ntm - xm + gm - 1) / gm : 0, cn = xn < ntn ? (ntn - xn + gn - 1) / gn : 0;
@@ -564,41 +582,33 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
 }
 
 
-// ---- ping-pong GEMM for large M: 256x256x64 tiles, two wave groups half a phase apart ---------------------
-// The 8 waves form 2 (m) x 4 (n) with a 128x64 output each; waves w and w+4 share a SIMD and belong to different
-// groups (wr = w >> 2). A K-tile is consumed in 4 phases, one 64x32 quadrant of the wave tile each (16 MFMAs); every
-// phase is a LOAD segment (LDS fragment reads for its quadrant + 2 DMA pieces of a half-tile two K-tiles ahead) and an
-// MFMA segment, each closed by a workgroup barrier. Group 1 executes one extra barrier up front, so while one wave of
-// a SIMD runs its 16 MFMAs the other one does its LDS reads / DMA issue: the matrix pipe always has a wave on it and
-// the loads never sit in front of MFMAs of the same wave (the one-phase-for-all kernel above idles the pipe whenever
-// both waves of a SIMD read LDS at the same time).
-// LDS: 2 slots x [A0 A1 B0 B1] half-tiles of 128 rows x 64 k (16 KiB each, rows XOR-swizzled in the DMA source
-// address). Wave group wr reads only A-half wr; waves wc read B-half wc >> 1.
-// Tick algebra (tick = barrier interval; group 0 runs L_p(T) at tick 8T+2p, M_p(T) at 8T+2p+1, group 1 one later):
-//   reads:  L_0 A-sub0 + B-sub0, L_1 B-sub1, L_2 A-sub1, L_3 none (B-sub0 stays in registers for quadrant (1,0))
-//   DMA  :  L_3(T) B0(T+2), L_0(T+1) B1(T+2), L_1(T+1) A0(T+2), L_2(T+1) A1(T+2)  -- every region is re-filled >= 2
-//           ticks after its last reader retired its reads (lgkmcnt(0) at the top of the following M segment)
-//   waits:  end of L_3(T): vmcnt(4) -> this wave's B0,B1,A0 pieces of K-tile T+1 landed; end of M_3(T): vmcnt(2) ->
-//           its A1 pieces too; both precede, by a barrier, the first read of that data by ANY wave.
-// Persistent over (tile, K-tile) like gemm_persist_kernel (same XCD grid); the epilogue of quadrant q is deferred to
-// L_q of the next tile's first K-tile (its accumulators are not touched before M_q), under the other group's MFMAs.
-// Measured (round 1, scripts/gpu_gemm_bench.py, back-to-back launches): a barrier interval costs ~650-850 cycles here
-// against the 256 its 16 MFMAs need -- removing the DMA, the MFMAs or the fragment reads each recovers only 10-20 %, so
-// it is the 8-barriers-per-K-tile skeleton itself. At 20.6k rows (the retrieval loop: 1-4 tiles per workgroup) it
-// loses to gemm_persist_kernel (qkv 121 vs 99 us, ffn2 178 vs 112 us); at 65k rows it wins by 5-11 % because a 256x256
-// tile moves 1/3 fewer L2->LDS bytes per flop. launch_gemm therefore uses it for >= 48k rows only (corpus encoding).
-constexpr int kPPHalf = 128 * 128;        // bytes of one half-tile
-constexpr int kPPSlot = 4 * kPPHalf;      // A0 A1 B0 B1
-constexpr int kPPLds = 2 * kPPSlot;       // 128 KiB
+// ---- persistent 256x256x64 GEMM, one phase for all waves, half-step refill ------------------------------------
+// gemm_persist_kernel's structure (every wave interleaves its own DMA pieces with its MFMAs, so the L2->LDS path is
+// always fed) on a 256x256 tile, which moves 1/3 fewer L2->LDS bytes per flop -- the measured bound of that kernel.
+// Only two 64 KiB slots fit in LDS; what makes two enough is that a K-step consumes its slot early: the step is four
+// sub-phases of 16 MFMAs per wave, (k-half 0 | 1) x (m-fragments 0-3 | 4-7), and the LDS reads of sub-phase i+1 are
+// issued at the top of sub-phase i, so after barrier B (top of sub-phase 4) the slot is free and its refill with
+// K-tile T+2 starts while the MFMAs of step T are still running:
+//   barrier A (top of step T, after vmcnt(2)): K-tile T landed            barrier B: every wave's reads of slot s retired
+//   DMA pieces (8 per wave and step, 2 per sub-phase): sub-phases 1-3 of step T carry K-tile T+1 (slot s^1, freed at
+//   barrier B of step T-1), sub-phase 4 the first quarter of K-tile T+2 (slot s).
+// Measured (round 1, scripts/gpu_gemm_bench.py): 9-31 % faster than gemm_persist_kernel at 65k rows (qkv 286 vs 350 us,
+// ffn1 382 vs 499 us); at 20k rows the 256x256 tile count quantises badly over 8 XCDs x 32 workgroups, so launch_gemm
+// compares the two kernels' round counts per call. A ping-pong variant (two wave groups half a phase apart, 8 barrier
+// intervals of 16 MFMAs per K-tile) was slower than both: a barrier interval cost 650-850 cycles against the 256 of
+// its MFMAs whichever of DMA / MFMA / LDS reads was removed -- the barrier skeleton itself; removed.
+using GemmB2 = GemmCfg<256, 256, 2, 4, 2>;
 
 template <int EPI>
 __global__ void __launch_bounds__(512)
-gemm_pp_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M_cap,
-               const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo, int gn) {
+gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M_cap,
+                const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo, int gn) {
+    using C = GemmB2;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    float* lds_bias = (float*)(lds + kPPLds);
+    float* lds_bias = (float*)(lds + C::LDS_BYTES);
     const int M = M_dev ? min(*M_dev, M_cap) : M_cap;
     const int ntn = N / 256, ntm = (M + 255) / 256;
+    gn = pick_gn_device(ntm, ntn, gn, gridDim.x >> 3);
     const int gm = 8 / gn;
     const int xcd = blockIdx.x & 7, xm = xcd / gn, xn = xcd % gn;
     const int cm = xm < ntm ? (ntm - xm + gm - 1) / gm : 0, cn = xn < ntn ? (ntn - xn + gn - 1) / gn : 0;
@@ -611,47 +621,40 @@ gemm_pp_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restri
         m0 = (xm + (l / cn) * gm) * 256;
         n0 = (xn + (l % cn) * gn) * 256;
     };
-    const int KT = K / BK;  // even (launch_gemm checks K % 128 == 0)
+    const int KT = K / BK;
     const int total = n_my * KT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave >> 2, wc = wave & 3;  // 2 (m) x 4 (n) waves, 128 x 64 outputs each
     const int g = lane >> 4, lr = lane & 15;
 
     for (int i = tid; i < N; i += 512) lds_bias[i] = bias[i];
 
-    // ---- loader ----
-    const int ld_row = tid >> 3;                         // row of this thread's piece within a 64-row group
-    const int ld_chunk = ((tid & 7) ^ (ld_row & 7)) * 8; // swizzled k-chunk (elements) it fetches
-    unsigned a_off[2][2];  // element offsets of this thread's A pieces (rows clamped to M - 1); 32-bit: A spans < 2^32 elements
+    // ---- loader: piece i of A / W = rows 64 i + (tid >> 3), 16-B chunk (tid & 7) ^ (row & 7) ----
+    const int ld_row = tid >> 3;
+    const int ld_chunk = ((tid & 7) ^ (ld_row & 7)) * 8;
+    unsigned a_off[4];  // element offsets (rows clamped to M - 1)
     unsigned w_off = 0;
-    int ld_tile = 0, ld_kt = 0, ld_T = 0;  // K-tile the next half-tile issue belongs to
+    int ld_tile = 0, ld_kt = 0, ld_T = 0;  // K-tile the NEXT quarter (2 pieces per wave-thread) belongs to
     auto set_load_tile = [&](int j) __attribute__((always_inline)) {
         int m0, n0;
         tile_origin(j, m0, n0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int ar = m0 + 128 * h + 64 * i + ld_row;
-                ar = ar < M ? ar : M - 1;  // rows past M are computed on a valid row and never stored
-                a_off[h][i] = (unsigned)ar * (unsigned)lda + (unsigned)ld_chunk;
-            }
+        for (int i = 0; i < 4; ++i) {
+            int ar = m0 + 64 * i + ld_row;
+            ar = ar < M ? ar : M - 1;
+            a_off[i] = (unsigned)ar * (unsigned)lda + (unsigned)ld_chunk;
+        }
         w_off = (unsigned)(n0 + ld_row) * (unsigned)K + (unsigned)ld_chunk;
     };
-    // region r in issue order: 0 = B0, 1 = B1, 2 = A0, 3 = A1 of K-tile ld_T (slot ld_T & 1)
-    auto issue_half = [&](int r) __attribute__((always_inline)) {
-        char* slot = lds + (ld_T & 1) * kPPSlot;
+    // piece c (0..7) of the loader's K-tile: 0-3 = A rows 64c.., 4-7 = W rows 64(c-4)..
+    auto issue_piece = [&](int c) __attribute__((always_inline)) {
+        char* slot = lds + (ld_T & 1) * C::STAGE_BYTES;
         const int k0 = ld_kt * BK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const _Float16* src = r < 2 ? W + (w_off + (unsigned)((128 * r + 64 * i) * K + k0)) : A + (a_off[r - 2][i] + (unsigned)k0);
-            char* dst = slot + (r < 2 ? (2 + r) : (r - 2)) * kPPHalf + (i * 512 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds(MDR_GPTR(src), MDR_LPTR(dst), 16, 0, 0);
-        }
+        const _Float16* src = c < 4 ? A + (a_off[c] + (unsigned)k0) : W + (w_off + (unsigned)(64 * (c - 4) * K + k0));
+        char* dst = slot + (c < 4 ? 0 : C::A_BYTES) + ((c & 3) * 512 + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds(MDR_GPTR(src), MDR_LPTR(dst), 16, 0, 0);
     };
-    // move the loader to the next K-tile; past the end of the stream it stays on the last one (surplus pieces land in
-    // free regions and are never read: the DMA count per phase stays constant, so the counted waits stay exact)
     auto next_ktile = [&]() __attribute__((always_inline)) {
         ++ld_T;
         if (ld_T < total) {
@@ -659,149 +662,106 @@ gemm_pp_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restri
         }
     };
 
-    // ---- reader offsets (bytes within a slot) ----
-    const int a_rd = wr * kPPHalf + lr * 128;
-    const int b_rd = (2 + (wc >> 1)) * kPPHalf + ((wc & 1) * 64 + lr) * 128;
+    const int a_rd = (wr * 128 + lr) * 128, w_rd = C::A_BYTES + (wc * 64 + lr) * 128;
     const int sw0 = ((0 * 4 + g) ^ (lane & 7)) << 4, sw1 = ((1 * 4 + g) ^ (lane & 7)) << 4;
 
-    f32x4 acc[2][2][4][2];  // [qi][qj][m-frag][n-frag]
-    half8 af[4][2];         // A fragments of the current row-half: [m-frag][k-half]
-    half8 bf[2][2][2];      // W fragments of both column-halves: [qj][n-frag][k-half]
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bias loads, before any DMA is in flight
+    set_load_tile(0);
+    // prologue: K-tile 0 completely, then the first 6 pieces of K-tile 1 (what sub-phases 1-3 of a step -1 would have issued)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) issue_piece(c);
+    next_ktile();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) issue_piece(c);  // "sub-phase 4 of step -1"
 
-    auto read_a = [&](const char* slot, int qi) __attribute__((always_inline)) {
+    f32x4 acc[8][4];
+    half8 wf0[4], wf1[4], af_a[4], af_b[4];
+    // 16 MFMAs (4 m-fragments from mbase x 4 n-fragments) with DMA pieces pc, pc+1 pinned after the 2nd and 4th group
+    auto sub_phase = [&](auto zero_c, int mbase, const half8* wfr, const half8* afr, int pc) __attribute__((always_inline)) {
+        constexpr bool Z = decltype(zero_c)::value;  // first K-tile of an output tile: accumulate onto 0
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-            af[mf][0] = *(const half8*)(slot + a_rd + (64 * qi + 16 * mf) * 128 + sw0);
-            af[mf][1] = *(const half8*)(slot + a_rd + (64 * qi + 16 * mf) * 128 + sw1);
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[mbase + q][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfr[n], afr[q], Z ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mbase + q][n], 0, 0, 0);
+            if (q == 1) issue_piece(pc);
+            if (q == 3) issue_piece(pc + 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto read_b = [&](const char* slot, int qj) __attribute__((always_inline)) {
+    int kt = 0, tile = 0;
+    for (int T = 0; T < total; ++T) {
+        const char* slot = lds + (T & 1) * C::STAGE_BYTES;
+        const bool first = kt == 0;
+        // barrier A: K-tile T landed (at most the 2 pieces issued in the previous sub-phase 4 may still fly)
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // reads for sub-phases 1 and 2
 #pragma unroll
-        for (int nf = 0; nf < 2; ++nf) {
-            bf[qj][nf][0] = *(const half8*)(slot + b_rd + (32 * qj + 16 * nf) * 128 + sw0);
-            bf[qj][nf][1] = *(const half8*)(slot + b_rd + (32 * qj + 16 * nf) * 128 + sw1);
-        }
-    };
-    auto mma = [&](int qi, int qj, bool first) __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio(1);
-        if (first) {
+        for (int q = 0; q < 4; ++q) wf0[q] = *(const half8*)(slot + w_rd + q * 16 * 128 + sw0);
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf)
+        for (int q = 0; q < 4; ++q) af_a[q] = *(const half8*)(slot + a_rd + q * 16 * 128 + sw0);
 #pragma unroll
-                for (int nf = 0; nf < 2; ++nf)
-                    acc[qi][qj][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[qj][nf][0], af[mf][0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        } else {
+        for (int q = 0; q < 4; ++q) af_b[q] = *(const half8*)(slot + a_rd + (4 + q) * 16 * 128 + sw0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- sub-phase 1: k-half 0, m-fragments 0-3; pieces 2,3 of the loader's K-tile (T+1)
+        if (first) sub_phase(std::true_type{}, 0, wf0, af_a, 2);
+        else sub_phase(std::false_type{}, 0, wf0, af_a, 2);
+        // reads for sub-phase 3 (k-half 1): W fragments, A fragments 0-3 into the registers sub-phase 1 just released
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf)
+        for (int q = 0; q < 4; ++q) wf1[q] = *(const half8*)(slot + w_rd + q * 16 * 128 + sw1);
 #pragma unroll
-                for (int nf = 0; nf < 2; ++nf)
-                    acc[qi][qj][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[qj][nf][0], af[mf][0], acc[qi][qj][mf][nf], 0, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q) af_a[q] = *(const half8*)(slot + a_rd + q * 16 * 128 + sw1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- sub-phase 2: k-half 0, m-fragments 4-7; pieces 4,5
+        if (first) sub_phase(std::true_type{}, 4, wf0, af_b, 4);
+        else sub_phase(std::false_type{}, 4, wf0, af_b, 4);
+        // reads for sub-phase 4: the LAST reads of this slot
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf)
+        for (int q = 0; q < 4; ++q) af_b[q] = *(const half8*)(slot + a_rd + (4 + q) * 16 * 128 + sw1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- sub-phase 3: k-half 1, m-fragments 0-3; pieces 6,7 complete K-tile T+1
+        sub_phase(std::false_type{}, 0, wf1, af_a, 6);
+        next_ktile();
+        // barrier B: every wave's reads of this slot have retired -> it may be refilled (K-tile T+2)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- sub-phase 4: k-half 1, m-fragments 4-7; pieces 0,1 of K-tile T+2
+        sub_phase(std::false_type{}, 4, wf1, af_b, 0);
+        if (++kt == KT) {
+            kt = 0;
+            int m0, n0;
+            tile_origin(tile, m0, n0);
+            ++tile;
+            // epilogue under the loads in flight: lane holds C[m = .. + lr][n = .. + 4g + r]
 #pragma unroll
-            for (int nf = 0; nf < 2; ++nf)
-                acc[qi][qj][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[qj][nf][1], af[mf][1], acc[qi][qj][mf][nf], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // epilogue of one quadrant: lane holds C[m = .. + lr][n = .. + 4g + r]
-    auto store_quadrant = [&](int qi, int qj, int m0, int n0) __attribute__((always_inline)) {
+            for (int mt = 0; mt < 8; ++mt) {
+                const int m = m0 + wr * 128 + mt * 16 + lr;
+                if (m >= M) continue;
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-            const int m = m0 + 128 * wr + 64 * qi + 16 * mf + lr;
-            if (m >= M) continue;
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n = n0 + wc * 64 + nt * 16 + 4 * g;
+                    const f32x4 b4 = *(const f32x4*)(lds_bias + n);
+                    f32x4 v = acc[mt][nt] + b4;
+                    if (EPI == EPI_BIAS_GELU_F16) {
 #pragma unroll
-            for (int nf = 0; nf < 2; ++nf) {
-                const int n = n0 + 64 * wc + 32 * qj + 16 * nf + 4 * g;
-                const f32x4 b4 = *(const f32x4*)(lds_bias + n);
-                f32x4 v = acc[qi][qj][mf][nf] + b4;
-                if (EPI == EPI_BIAS_GELU_F16) {
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    }
+                    if (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
+                        half4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                }
-                if (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
-                    half4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
-                    *(half4*)((_Float16*)out + (size_t)m * ldo + n) = o;
-                } else {
-                    *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
+                        for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
+                        *(half4*)((_Float16*)out + (size_t)m * ldo + n) = o;
+                    } else {
+                        *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
+                    }
                 }
             }
         }
-    };
-
-    // ---- prologue: K-tiles 0 and 1 ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bias loads, before any DMA is in flight
-    set_load_tile(0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) issue_half(r);
-    next_ktile();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) issue_half(r);
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");  // K-tile 0 landed (this wave's pieces)
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier interval behind group 0
-    asm volatile("" ::: "memory");
-
-    int prev_m0 = 0, prev_n0 = 0, kt = 0, tile = 0;
-    bool have_prev = false;
-    // one K-tile; `slot` is compile-time (the stream is walked two K-tiles per loop iteration)
-    auto ktile = [&](const char* slot) __attribute__((always_inline)) {
-        const bool first = kt == 0;
-        const bool flush = first && have_prev;
-        // ---- phase 0: quadrant (0,0)
-        if (flush) store_quadrant(0, 0, prev_m0, prev_n0);
-        read_b(slot, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(slot, 0);
-        issue_half(1);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mma(0, 0, first);
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 1: quadrant (0,1)
-        if (flush) store_quadrant(0, 1, prev_m0, prev_n0);
-        read_b(slot, 1);
-        issue_half(2);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mma(0, 1, first);
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 2: quadrant (1,1)
-        if (flush) store_quadrant(1, 1, prev_m0, prev_n0);
-        read_a(slot, 1);
-        issue_half(3);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mma(1, 1, first);
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 3: quadrant (1,0), W fragments of column-half 0 still in registers
-        if (flush) store_quadrant(1, 0, prev_m0, prev_n0);
-        next_ktile();
-        issue_half(0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        mma(1, 0, first);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (++kt == KT) {
-            kt = 0;
-            tile_origin(tile, prev_m0, prev_n0);
-            have_prev = true;
-            ++tile;
-        }
-    };
-    for (int T = 0; T < total; T += 2) {
-        ktile(lds);
-        ktile(lds + kPPSlot);
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's extra barrier
-    store_quadrant(0, 0, prev_m0, prev_n0);
-    store_quadrant(0, 1, prev_m0, prev_n0);
-    store_quadrant(1, 1, prev_m0, prev_n0);
-    store_quadrant(1, 0, prev_m0, prev_n0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus DMA pieces must have landed before the LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus pieces must have landed before the LDS is released
 }
 
 using GemmBig = GemmCfg<256, 256, 4, 2, 2>;
@@ -1051,20 +1011,39 @@ int launch_gemm_cfg(const _Float16* A, int lda, const _Float16* W, const float* 
     return MDR_OK;
 }
 
+// Rounds of tiles the busiest XCD's workgroups walk under the gm x gn XCD grid (see gemm_persist_kernel).
+inline int xcd_grid_rounds(int ntm, int ntn, int gn, int wgs_per_xcd) {
+    const int gm = 8 / gn;
+    const long long local = (long long)((ntm + gm - 1) / gm) * ((ntn + gn - 1) / gn);
+    return (int)((local + wgs_per_xcd - 1) / wgs_per_xcd);
+}
+// XCD columns: start from the L2 rule (the W slice an L2 must keep, N*K*2/gn bytes, <= 2.5 MiB), then take the gn with
+// the fewest rounds at the expected row count (ties keep the rule's choice). Uneven n splits are fine.
+inline int pick_gn(int M_est, int bm, int N, int bn, int K, int wgs_per_xcd, int* rounds_out) {
+    static int force_gn = getenv("MDR_GEMM_GN") ? atoi(getenv("MDR_GEMM_GN")) : 0;
+    const int ntm = (M_est + bm - 1) / bm, ntn = N / bn;
+    int gn = 1;
+    while (gn < 8 && (size_t)N * K * 2 / gn > (size_t)(5 << 19) && gn * 2 <= ntn) gn *= 2;
+    int best = gn, best_r = xcd_grid_rounds(ntm, ntn, gn, wgs_per_xcd);
+    for (int c = 1; c <= 8 && c <= ntn; c *= 2) {
+        const int r = xcd_grid_rounds(ntm, ntn, c, wgs_per_xcd);
+        if (r < best_r) { best = c; best_r = r; }
+    }
+    if (force_gn == 1 || force_gn == 2 || force_gn == 4 || force_gn == 8) { best = force_gn; best_r = xcd_grid_rounds(ntm, ntn, best, wgs_per_xcd); }
+    if (rounds_out) *rounds_out = best_r;
+    return best;
+}
+
 template <int EPI, typename C>
 int launch_gemm_persist(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
-                        int num_cus, hipStream_t st) {
+                        int M_est, int num_cus, hipStream_t st) {
     constexpr int lds = C::LDS_BYTES + kPersistBiasMax * 4;
     static bool attr = false;
     if (!attr) {
         MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI, C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    // XCD grid: split n over gn (a divisor of 8) XCD columns until the W slice an L2 must keep (N*K*2/gn bytes) is <= 2.5 MiB
-    static int force_gn = getenv("MDR_GEMM_GN") ? atoi(getenv("MDR_GEMM_GN")) : 0;
-    int gn = 1;
-    while (gn < 8 && (size_t)N * K * 2 / gn > (size_t)(5 << 19) && gn * 2 <= N / C::BN) gn *= 2;  // uneven n splits are fine
-    if (force_gn == 1 || force_gn == 2 || force_gn == 4 || force_gn == 8) gn = force_gn;
+    const int gn = pick_gn(M_est, C::BM, N, C::BN, K, num_cus / 8, nullptr);
     const int grid = num_cus / 8 * 8;
     hipLaunchKernelGGL((gemm_persist_kernel<EPI, C>), dim3(grid), dim3(C::THREADS), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, gn);
     MDR_HIP_TRY(hipGetLastError());
@@ -1072,20 +1051,17 @@ int launch_gemm_persist(const _Float16* A, int lda, const _Float16* W, const flo
 }
 
 template <int EPI>
-int launch_gemm_pp(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
-                   int num_cus, hipStream_t st) {
-    constexpr int lds = kPPLds + kPersistBiasMax * 4;
+int launch_gemm_big(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
+                    int M_est, int num_cus, hipStream_t st) {
+    constexpr int lds = GemmB2::LDS_BYTES + kPersistBiasMax * 4;
     static bool attr = false;
     if (!attr) {
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_big_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    static int force_gn = getenv("MDR_GEMM_GN") ? atoi(getenv("MDR_GEMM_GN")) : 0;
-    int gn = 1;
-    while (gn < 8 && (size_t)N * K * 2 / gn > (size_t)(5 << 19) && gn * 2 <= N / 256) gn *= 2;
-    if (force_gn == 1 || force_gn == 2 || force_gn == 4 || force_gn == 8) gn = force_gn;
+    const int gn = pick_gn(M_est, 256, N, 256, K, num_cus / 8, nullptr);
     const int grid = num_cus / 8 * 8;
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(grid), dim3(512), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, gn);
+    hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(grid), dim3(512), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, gn);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }
@@ -1095,21 +1071,27 @@ int launch_gemm_pp(const _Float16* A, int lda, const _Float16* W, const float* b
 template <int EPI>
 int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
                 const _Float16* res, int ldr, int M_est, int num_cus, hipStream_t st, bool* res_added = nullptr, int force = -1) {
-    // experiment knob: 1 small, 2 mid, 3 big tiles; 4 persistent / 5 ping-pong for the large-M calls (the others keep the heuristic)
+    // experiment knob: 1 small, 2 mid, 3 big tiles; 4 persistent 256x128 / 6 persistent 256x256 for the large-M calls (the others keep the heuristic)
     static int env_sel = getenv("MDR_GEMM_CFG") ? atoi(getenv("MDR_GEMM_CFG")) : 0;
     int sel = force >= 0 ? force : env_sel;
-    if (force < 0 && (sel == 4 || sel == 5) && (long long)(N / 128) * ((M_est + 255) / 256) < (long long)num_cus * 3 / 2) sel = 0;
+    if (force < 0 && (sel == 4 || sel == 6) && (long long)(N / 128) * ((M_est + 255) / 256) < (long long)num_cus * 3 / 2) sel = 0;
     if (res_added) *res_added = true;
     const long long p_tiles = (long long)(N / 128) * ((M_est + 255) / 256);
-    if ((sel == 4 || sel == 5 || (sel == 0 && p_tiles >= (long long)num_cus * 3 / 2)) && N % 128 == 0 && N <= kPersistBiasMax) {
+    if ((sel == 4 || sel == 6 || (sel == 0 && p_tiles >= (long long)num_cus * 3 / 2)) && N % 128 == 0 && N <= kPersistBiasMax) {
         if (res_added) *res_added = false;
         else if (EPI == EPI_BIAS_RES_F32) return set_error(MDR_E_STATE, "large-M GEMM with a residual needs the caller to take the residual (res_added)");
         constexpr int E = EPI == EPI_BIAS_RES_F32 ? EPI_BIAS_F32 : EPI;
-        // the 256x256 ping-pong kernel wins once every workgroup walks several tiles (measured: +5..11 % at 65k rows,
-        // -10..-40 % at 20k rows where a workgroup has 1-4 tiles): corpus-encoding batches, not the retrieval loop
-        if ((sel == 5 || (sel == 0 && M_est >= 49152)) && N % 256 == 0 && K % 128 == 0)
-            return launch_gemm_pp<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, num_cus, st);
-        return launch_gemm_persist<E, GemmP>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, num_cus, st);
+        // 256x256 tiles move 1/3 fewer L2->LDS bytes per flop (measured 0.82x the time per unit of work) but quantise worse
+        // over 8 XCDs x 32 workgroups: compare the round counts of the two kernels at the expected row count
+        if (sel == 6 || sel == 0) {
+            int r_big = 0, r_p = 0;
+            if (N % 256 == 0) {
+                pick_gn(M_est, 256, N, 256, K, num_cus / 8, &r_big);
+                pick_gn(M_est, 256, N, 128, K, num_cus / 8, &r_p);
+                if (sel == 6 || r_big * 2 * 0.82 < (double)r_p) return launch_gemm_big<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
+            }
+        }
+        return launch_gemm_persist<E, GemmP>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
     }
     const long long big_blocks = (N % 256 == 0) ? (long long)(N / 256) * ((M_est + 255) / 256) : 0;
     const long long mid_blocks = (long long)(N / 128) * ((M_est + 127) / 128);
@@ -1255,7 +1237,7 @@ int mdr_test_gemm_f16(const void* A_dev, const void* W_dev, const float* bias_de
     MDR_REQUIRE(A_dev && W_dev && bias_dev && out_dev, "NULL pointer");
     MDR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "bad GEMM shape M=%d N=%d K=%d (N, K multiples of 64)", M, N, K);
     MDR_REQUIRE(epilogue == EPI_BIAS_F16 || epilogue == EPI_BIAS_GELU_F16 || epilogue == EPI_BIAS_F32, "epilogue must be 0, 1 or 3");
-    MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 5, "kernel must be 0, 1, 2, 4 or 5");
+    MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 6, "kernel must be 0, 1, 2, 4 or 6");
     DeviceGuard guard(device);
     if (!guard.ok) return set_error(MDR_E_HIP, "hipSetDevice(%d) failed", device);
     hipDeviceProp_t prop;
