@@ -898,6 +898,158 @@ __global__ void __launch_bounds__(512) attention_kernel(const _Float16* __restri
     }
 }
 
+
+// ---- attention, streaming form: one workgroup per (sequence, head, block of 128 queries) ---------------------
+// K and V of a key chunk (<= 16*NTC keys) are staged ROW-major by LDS-DMA (global_load_lds, 16-B slots XOR-swizzled by
+// key & 7 in the source address, rows past the sequence clamped to its last row so that every staged value is finite),
+// 32 KiB + 32 KiB at NTC = 16: two workgroups share a CU, so one stages while the other computes (the one-shot kernel
+// above needs 98 KiB and serialises its own staging and compute on a CU; its V^T staging writes are 8-way conflicted).
+// S^T = K Q^T on MFMA as above; the V^T operand of O^T = V^T P^T is read straight from the row-major image with
+// ds_read_b64_tr_b16 (lane a of a 16-lane group addresses row a >> 2, columns 4 (a & 3).. of a [4 keys][16 d] block and
+// receives column a: measured semantics, conflict-free with the key & 7 swizzle). Longer sequences take several chunks
+// with the usual running (max, sum) rescale; probabilities enter the PV product as fp16 of exp(s - max) <= 1 and the
+// 1 / sum is applied to the fp32 result.
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+template <int NTC>  // key tiles of 16 per chunk
+__global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
+                                                               _Float16* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int KC = NTC * 16;
+    char* Ks = lds;              // [KC][64] halfs, 128-B rows
+    char* Vs = lds + KC * 128;   // same
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int start = cu[b], len = cu[b + 1] - start;
+    const int qb0 = blockIdx.z * 128;
+    if (qb0 >= len) return;
+    const int H3 = 3 * H;
+    const int q0 = qb0 + wave * 16;
+    const bool wave_valid = q0 < len;  // waves past the sequence only help staging
+    const int qi = q0 + lr;
+    const bool qvalid = qi < len;
+    const int qrow = qvalid ? qi : len - 1;
+    half8 qf[2];
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const half8*)(qkv + (size_t)(start + qrow) * H3 + h * 64 + ds * 32 + g * 8);
+    // retire the Q loads before any DMA is in flight (a pending register load would make the compiler drain the DMA later)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) asm volatile("" : "+v"(qf[ds]));
+
+    // DMA plan: wave-instruction i covers LDS slots 64 i .. 64 i + 63 = rows 8 i .. 8 i + 7; this lane: row 8 i + (lane >> 3),
+    // slot lane & 7 holding source chunk (lane & 7) ^ (row & 7) = (lane & 7) ^ (lane >> 3)
+    const int st_row = lane >> 3;
+    const int st_col = ((lane & 7) ^ st_row) * 8;
+    // reader offsets
+    const int k_rd = lr * 128;                       // + t * 2048 + (((ds * 4 + g) ^ (lr & 7)) << 4)
+    const int ksw0 = ((0 * 4 + g) ^ (lr & 7)) << 4, ksw1 = ((1 * 4 + g) ^ (lr & 7)) << 4;
+    const int vkey = 4 * g + (lr >> 2);              // key within a 16-key half of a pair-tile
+    const int vsw = vkey & 7;
+    int v_rd[4];                                     // byte offset of this lane's 8-B piece for d-tile dt, relative to the pair-tile row base
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) v_rd[dt] = vkey * 128 + ((((dt * 2 + ((lr & 3) >> 1)) ^ vsw)) << 4) + (lr & 1) * 8;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kc0 = 0; kc0 < len; kc0 += KC) {
+        const int ck = min(KC, len - kc0);     // keys of this chunk
+        const int nt = (ck + 15) >> 4;
+        const int np = (nt + 1) >> 1;
+        if (kc0 > 0) __syncthreads();          // every wave is done reading the previous chunk
+        // ---- stage K and V rows kc0 .. kc0 + 32 np - 1 (clamped to len - 1)
+        for (int i = wave; i < np * 4; i += 8) {
+            int row = kc0 + i * 8 + st_row;
+            row = row < len ? row : len - 1;
+            const _Float16* src = qkv + (size_t)(start + row) * H3 + H + h * 64 + st_col;
+            __builtin_amdgcn_global_load_lds(MDR_GPTR(src), MDR_LPTR(Ks + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(MDR_GPTR(src + H), MDR_LPTR(Vs + i * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (!wave_valid) continue;
+
+        // ---- S^T tiles of this chunk: lane holds keys kc0 + 16 t + 4 g + r for query lr
+        f32x4 s[NTC];
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) {
+            s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (t < nt) {
+                const half8 k0 = *(const half8*)(Ks + k_rd + t * 2048 + ksw0);
+                const half8 k1 = *(const half8*)(Ks + k_rd + t * 2048 + ksw1);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kc0 + t * 16 + 4 * g + r;
+                    s[t][r] = key < len ? acc[r] * 0.125f : -INFINITY;
+                    cmax = fmaxf(cmax, s[t][r]);
+                }
+            }
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+        const float m_new = fmaxf(m_run, cmax);  // finite: every chunk holds at least one valid key
+        const float alpha = exp2f((m_run - m_new) * 1.4426950408889634f);  // 0 on the first chunk
+        float csum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NTC; ++t)
+            if (t < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f((s[t][r] - m_new) * 1.4426950408889634f);
+                    s[t][r] = e;
+                    csum += e;
+                }
+            }
+        csum += __shfl_xor(csum, 16);
+        csum += __shfl_xor(csum, 32);
+        l_run = l_run * alpha + csum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+
+        // ---- O^T += V^T P^T. k-slot (g, j) of both operands <-> key 32 pt + (j < 4 ? 4g + j : 16 + 4g + j - 4): the P operand
+        // is this lane's own S^T registers, the V^T operand two transposing reads of the row-major V image
+#pragma unroll
+        for (int pt = 0; pt < NTC / 2; ++pt)
+            if (pt < np) {
+                half8 pf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pf[j] = (_Float16)s[2 * pt][j];
+                    pf[4 + j] = (2 * pt + 1 < nt) ? (_Float16)s[2 * pt + 1][j] : (_Float16)0.f;
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const char* vp = Vs + pt * 4096 + v_rd[dt];
+                    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)vp);
+                    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vp + 2048));
+                    const half8 vf = {(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3],
+                                      (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+    }
+    if (qvalid) {
+        const float inv = 1.f / l_run;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            half4 w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = (_Float16)(o[dt][r] * inv);
+            *(half4*)(ctx + (size_t)(start + qi) * H + h * 64 + dt * 16 + 4 * g) = w;
+        }
+    }
+}
+
 // Last layer: only the CLS row of each sequence feeds the projection head, so its attention needs ONE query per
 // (sequence, head). One wave per (sequence, head): scores over the keys (lane = key), softmax, then lane = feature.
 __global__ void __launch_bounds__(64) attention_cls_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
@@ -1115,6 +1267,20 @@ int launch_attention(const _Float16* qkv, const int* cu, int B, int L, int H, in
     return MDR_OK;
 }
 
+template <int NTC>
+int launch_attention_stream(const _Float16* qkv, const int* cu, int B, int L, int H, int heads, _Float16* ctx, hipStream_t st) {
+    static bool attr = false;
+    constexpr int lds = NTC * 16 * 128 * 2;
+    if (!attr) {
+        MDR_HIP_TRY(hipFuncSetAttribute((const void*)attention_stream_kernel<NTC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    dim3 grid(heads, B, (L + 127) / 128);
+    hipLaunchKernelGGL((attention_stream_kernel<NTC>), grid, dim3(512), lds, st, qkv, cu, H, ctx);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
 const mdr_tensor* find_tensor(const mdr_tensor* ts, int n, const std::string& name) {
     for (int i = 0; i < n; ++i)
         if (ts[i].name && name == ts[i].name) return &ts[i];
@@ -1316,7 +1482,11 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
             MDR_HIP_TRY(hipGetLastError());
             break;
         }
-        if (L <= 128) rc = launch_attention<8>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
+        static const int attn_sel = getenv("MDR_ATTN") ? atoi(getenv("MDR_ATTN")) : 0;  // experiment knob: 1 = one-shot kernel, 2 = streaming kernel
+        if (attn_sel == 2 || (attn_sel == 0 && L > 128)) {
+            rc = L <= 64 ? launch_attention_stream<4>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st)
+                         : launch_attention_stream<16>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
+        } else if (L <= 128) rc = launch_attention<8>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         else if (L <= 384) rc = launch_attention<24>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         else rc = launch_attention<32>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         if (rc) return rc;
