@@ -387,22 +387,6 @@ gemm_f16_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
     }
 }
 
-// XCD columns, decided on the device (the packed row count is only known there): among gn = 1, 2, 4, 8 (<= n-tiles) take
-// the one whose busiest XCD walks the fewest rounds of tiles; ties go to gn_rule (the host's L2-capacity choice), then
-// to the smaller gn. Every workgroup evaluates the same expression, so they all agree.
-__device__ inline int pick_gn_device(int ntm, int ntn, int gn_rule, int wgs_per_xcd) {
-    int best = gn_rule, best_r = 0x7fffffff;
-#pragma unroll
-    for (int c = 1; c <= 8; c *= 2) {
-        if (c > ntn && c != 1) continue;
-        const int gm = 8 / c;
-        const int local = ((ntm + gm - 1) / gm) * ((ntn + c - 1) / c);
-        const int r = (local + wgs_per_xcd - 1) / wgs_per_xcd;
-        if (r < best_r || (r == best_r && c == gn_rule)) { best = c; best_r = r; }
-    }
-    return best;
-}
-
 // ---- persistent GEMM for large M ------------------------------------------------------------------------
 // K is short here (768 or 3072): a one-tile-per-block kernel spends as long filling and draining its LDS ring
 // as computing. This kernel keeps ONE 512-thread block per CU alive and walks (tile, k-step) as one flat stream:
@@ -419,30 +403,29 @@ constexpr int kPersistBiasMax = 3072;  // floats of bias kept in LDS behind the 
 template <int EPI, typename C>
 __global__ void __launch_bounds__(C::THREADS)
 gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M_cap,
-                    const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo, int gn) {
+                    const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo, int epi_mode) {
     static_assert(C::MT == 4 && (C::NT == 4 || C::NT == 8) && C::A_CHUNKS == 4 && C::W_CHUNKS <= 4, "the pinned K-step below is written for these shapes");
     constexpr int MT = C::MT, NT = C::NT, SLOTS = C::STAGES, AHEAD = SLOTS - 1;  // batches issued ahead of the one being computed
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* lds_bias = (float*)(lds + C::LDS_BYTES);
     const int M = M_dev ? min(*M_dev, M_cap) : M_cap;
-    // XCD-aware tile assignment. Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only) and each
-    // XCD has a private 4 MiB L2. The 8 XCDs form a gm x gn grid over (m-tiles, n-tiles): XCD (xm, xn) owns m-tiles
-    // xm, xm+gm, .. and n-tiles xn, xn+gn, .., walked m-major by its G/8 workgroups, so the blocks sharing an A tile run
-    // on ONE L2 at the same time and each L2 only ever holds 1/gn of W. Without it every XCD pulled all of A through the
-    // fabric (measured: 8x the algorithmic A traffic, the FFN2 GEMM ran at the fabric's 5.8 TB/s).
+    // XCD-aware tile assignment. Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only) and each XCD
+    // has a private 4 MiB L2. Tiles are numbered m-major (n fastest); XCD x owns the contiguous eighth [T x / 8, T (x+1) / 8)
+    // of that order and its G / 8 workgroups walk it round-robin: the workgroups sharing an A tile run on ONE L2 at the same
+    // time (without that every XCD pulled all of A through the fabric: measured 8x the algorithmic A traffic), and no XCD
+    // has more than one tile above the average -- the earlier gm x gn grid of XCDs lost up to a whole round of tiles to
+    // rounding at 20 k rows (3 rounds instead of 2 for the out-projection).
     const int ntn = N / C::BN, ntm = (M + C::BM - 1) / C::BM;
-    gn = pick_gn_device(ntm, ntn, gn, gridDim.x >> 3);
-    const int gm = 8 / gn;
-    const int xcd = blockIdx.x & 7, xm = xcd / gn, xn = xcd % gn;
-    const int cm = xm < ntm ? (ntm - xm + gm - 1) / gm : 0, cn = xn < ntn ? (ntn - xn + gn - 1) / gn : 0;
+    const long long T_all = (long long)ntm * ntn;
+    const int xcd = blockIdx.x & 7;
+    const int t_base = (int)(T_all * xcd / 8), local_tiles = (int)(T_all * (xcd + 1) / 8) - t_base;
     const int lb = blockIdx.x >> 3, G = gridDim.x >> 3;  // this XCD's workgroups
-    const int local_tiles = cm * cn;
     if (lb >= local_tiles) return;
     const int n_my = (local_tiles - lb + G - 1) / G;
     auto tile_origin = [&](int j, int& m0, int& n0) {
-        const int l = lb + j * G;
-        m0 = (xm + (l / cn) * gm) * C::BM;
-        n0 = (xn + (l % cn) * gn) * C::BN;
+        const int t = t_base + lb + j * G;
+        m0 = (t / ntn) * C::BM;
+        n0 = (t % ntn) * C::BN;
     };
     const int KT = K / BK;
     const int total_steps = n_my * KT;
@@ -503,6 +486,31 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
             __builtin_amdgcn_global_load_lds(MDR_GPTR(w_src[i] + k0), MDR_LPTR(base + C::A_BYTES + (i * C::THREADS + wave * 64) * 16), 16, 0, 0);
         loader_done();
     }
+    // Deferred epilogue: the finished tile's results wait in registers (bias / GELU applied, converted to the output type)
+    // and leave two fragments per K-step at the TOP of the next tile's steps, before that step's DMA pieces. Stored right
+    // after the tile instead, the 16 stores are the youngest VMEM ops at the next counted vmcnt wait, which then has to
+    // drain every DMA batch in flight plus the stores (measured: 25-30 % of the K = 768 GEMMs).
+    constexpr bool F16OUT = EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16;
+    using pend_t = typename std::conditional<F16OUT, half4, f32x4>::type;
+    pend_t pend[MT * NT];
+    int pend_m0 = 0, pend_n0 = 0, pend_left = 0;  // fragments of the previous tile not stored yet (wave-uniform)
+    bool pend_full = false;      // that tile lies completely below M: its stores are unconditional, so their COUNT is known
+    bool stored_two = false;     // the previous K-step issued exactly two (unconditional) stores before its DMA pieces
+    auto store_pending = [&](int f, bool check) __attribute__((always_inline)) {  // f compile-time after inlining
+        const int mt = f / NT, nt = f % NT;
+        const int m = pend_m0 + (wm * MT + mt) * 16 + lr;
+        const int n = pend_n0 + (wn * NT + nt) * 16 + 4 * g;
+        if (!check || m < M) {
+            if (F16OUT) *(pend_t*)((_Float16*)out + (size_t)m * ldo + n) = pend[f];
+            else *(pend_t*)((float*)out + (size_t)m * ldo + n) = pend[f];
+        }
+    };
+    auto flush_pending = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int f = 0; f < MT * NT; ++f)
+            if (f >= MT * NT - pend_left) store_pending(f, true);
+        pend_left = 0;
+    };
     int step = 0;
     for (int j = 0; j < n_my; ++j) {
         int m0, n0;
@@ -515,9 +523,29 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
         for (int kt = 0; kt < KT; ++kt, ++step) {
             // batch `step` has landed; exactly one younger batch stays in flight across the barrier. Epilogue stores
             // issued since only make this wait more conservative (vmcnt completes in order).
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::PER_STAGE * (AHEAD - 1)) : "memory");
+            // (VMEM ops complete in order: when the previous step put exactly two stores in front of its DMA pieces they may
+            // stay outstanding with them -- the stores then have two K-steps to be acknowledged instead of one.)
+            if (stored_two)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::PER_STAGE * (AHEAD - 1) + 2) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::PER_STAGE * (AHEAD - 1)) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            stored_two = false;
+            if (pend_left > 0) {  // wave-uniform; fragments leave in order 0, 1, 2, ..: two per step
+                const bool chk = !pend_full;
+                stored_two = pend_full && epi_mode == 2;
+                switch (MT * NT - pend_left) {
+#define MDR_PEND_CASE(F) case F: if (F + 1 < MT * NT) { \
+        if (chk) { store_pending(F + 1 < MT * NT ? F : 0, true); store_pending(F + 1 < MT * NT ? F + 1 : 0, true); } \
+        else { store_pending(F + 1 < MT * NT ? F : 0, false); store_pending(F + 1 < MT * NT ? F + 1 : 0, false); } } break;
+                    MDR_PEND_CASE(0) MDR_PEND_CASE(2) MDR_PEND_CASE(4) MDR_PEND_CASE(6) MDR_PEND_CASE(8) MDR_PEND_CASE(10) MDR_PEND_CASE(12) MDR_PEND_CASE(14)
+                    MDR_PEND_CASE(16) MDR_PEND_CASE(18) MDR_PEND_CASE(20) MDR_PEND_CASE(22) MDR_PEND_CASE(24) MDR_PEND_CASE(26) MDR_PEND_CASE(28) MDR_PEND_CASE(30)
+#undef MDR_PEND_CASE
+                    default: break;
+                }
+                pend_left -= 2;
+            }
             advance_loader();
             // ---- one straight-line block: LDS fragment reads, 32 MFMAs, and the DMA pieces of batch step+AHEAD (into the
             // slot read at step-1, free since the barrier) spread BETWEEN the MFMAs. Issued in a burst right after the
@@ -553,11 +581,10 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
             }
             loader_done();
         }
-        // epilogue under the next tile's loads: lane holds C[m = .. + lr][n = .. + 4g + r]
+        // epilogue values -> pending registers (lane holds C[m = .. + lr][n = .. + 4g + r]); stores are deferred, see above
+        if (pend_left > 0) flush_pending();  // K shorter than 8 steps: the previous tile still has fragments left
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int m = m0 + (wm * MT + mt) * 16 + lr;
-            if (m >= M) continue;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = n0 + (wn * NT + nt) * 16 + 4 * g;
@@ -567,17 +594,23 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
                 }
-                if (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
+                if constexpr (F16OUT) {
                     half4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
-                    *(half4*)((_Float16*)out + (size_t)m * ldo + n) = o;
+                    pend[mt * NT + nt] = o;
                 } else {
-                    *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
+                    pend[mt * NT + nt] = v;
                 }
             }
         }
+        pend_m0 = m0;
+        pend_n0 = n0;
+        pend_left = MT * NT;
+        pend_full = m0 + C::BM <= M;
+        if (epi_mode == 0) flush_pending();  // measurement: store right after the tile
     }
+    flush_pending();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus batches must have landed before the LDS is released
 }
 
@@ -602,24 +635,22 @@ using GemmB2 = GemmCfg<256, 256, 2, 4, 2>;
 template <int EPI>
 __global__ void __launch_bounds__(512)
 gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M_cap,
-                const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo, int gn) {
+                const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo) {
     using C = GemmB2;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* lds_bias = (float*)(lds + C::LDS_BYTES);
     const int M = M_dev ? min(*M_dev, M_cap) : M_cap;
     const int ntn = N / 256, ntm = (M + 255) / 256;
-    gn = pick_gn_device(ntm, ntn, gn, gridDim.x >> 3);
-    const int gm = 8 / gn;
-    const int xcd = blockIdx.x & 7, xm = xcd / gn, xn = xcd % gn;
-    const int cm = xm < ntm ? (ntm - xm + gm - 1) / gm : 0, cn = xn < ntn ? (ntn - xn + gn - 1) / gn : 0;
+    const long long T_all = (long long)ntm * ntn;  // tile order and XCD ownership: see gemm_persist_kernel
+    const int xcd = blockIdx.x & 7;
+    const int t_base = (int)(T_all * xcd / 8), local_tiles = (int)(T_all * (xcd + 1) / 8) - t_base;
     const int lb = blockIdx.x >> 3, G = gridDim.x >> 3;
-    const int local_tiles = cm * cn;
     if (lb >= local_tiles) return;
     const int n_my = (local_tiles - lb + G - 1) / G;
     auto tile_origin = [&](int j, int& m0, int& n0) __attribute__((always_inline)) {
-        const int l = lb + j * G;
-        m0 = (xm + (l / cn) * gm) * 256;
-        n0 = (xn + (l % cn) * gn) * 256;
+        const int t = t_base + lb + j * G;
+        m0 = (t / ntn) * 256;
+        n0 = (t % ntn) * 256;
     };
     const int KT = K / BK;
     const int total = n_my * KT;
@@ -735,27 +766,48 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
             int m0, n0;
             tile_origin(tile, m0, n0);
             ++tile;
-            // epilogue under the loads in flight: lane holds C[m = .. + lr][n = .. + 4g + r]
+            // Epilogue under the loads in flight. The MFMA layout gives a lane 4 consecutive n of ONE row (8 B of f16): stored
+            // directly, a wave instruction touches 16 rows x 32 B = 16 partial cache lines, and the 256 such instructions of a
+            // tile cost the CU ~25 % of a K = 768 GEMM (measured by skipping them; they are line-REQUEST bound, not byte bound:
+            // deferring them over the next K-steps did not help). So each 16-row block goes through a 2 KiB per-wave LDS
+            // scratch (16-B chunks XOR-swizzled by row & 7) and leaves as 8 rows x 128 B = 8 full lines per instruction.
+            char* scr = lds + C::LDS_BYTES + kPersistBiasMax * 4 + wave * 2048;
+            const int rd_row = lane >> 3, rd_chunk = lane & 7;
+            constexpr bool F16OUT = EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16;
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
-                const int m = m0 + wr * 128 + mt * 16 + lr;
-                if (m >= M) continue;
+                const int mrow = m0 + wr * 128 + mt * 16;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int n = n0 + wc * 64 + nt * 16 + 4 * g;
-                    const f32x4 b4 = *(const f32x4*)(lds_bias + n);
-                    f32x4 v = acc[mt][nt] + b4;
-                    if (EPI == EPI_BIAS_GELU_F16) {
+                for (int hf = 0; hf < (F16OUT ? 1 : 2); ++hf) {  // f32 rows of 64 columns take two 128-B passes
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    for (int q = 0; q < (F16OUT ? 4 : 2); ++q) {
+                        const int nt = F16OUT ? q : 2 * hf + q;
+                        const int n = n0 + wc * 64 + nt * 16 + 4 * g;
+                        const f32x4 b4 = *(const f32x4*)(lds_bias + n);
+                        f32x4 v = acc[mt][nt] + b4;
+                        if (EPI == EPI_BIAS_GELU_F16) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                        }
+                        if constexpr (F16OUT) {
+                            half4 o;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
+                            *(half4*)(scr + lr * 128 + (((q * 2 + (g >> 1)) ^ (lr & 7)) << 4) + (g & 1) * 8) = o;
+                        } else {
+                            *(f32x4*)(scr + lr * 128 + (((q * 4 + g) ^ (lr & 7)) << 4)) = v;
+                        }
                     }
-                    if (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
-                        half4 o;
+                    // row r = rd_row (+8), 16-B chunk rd_chunk of the 128-B row block
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
-                        *(half4*)((_Float16*)out + (size_t)m * ldo + n) = o;
-                    } else {
-                        *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
+                    for (int half = 0; half < 2; ++half) {
+                        const int r = rd_row + 8 * half;
+                        const f32x4 val = *(const f32x4*)(scr + r * 128 + ((rd_chunk ^ (r & 7)) << 4));
+                        const int m = mrow + r;
+                        if (m < M) {
+                            if constexpr (F16OUT) *(f32x4*)((_Float16*)out + (size_t)m * ldo + n0 + wc * 64 + rd_chunk * 8) = val;
+                            else *(f32x4*)((float*)out + (size_t)m * ldo + n0 + wc * 64 + hf * 32 + rd_chunk * 4) = val;
+                        }
                     }
                 }
             }
@@ -1163,27 +1215,11 @@ int launch_gemm_cfg(const _Float16* A, int lda, const _Float16* W, const float* 
     return MDR_OK;
 }
 
-// Rounds of tiles the busiest XCD's workgroups walk under the gm x gn XCD grid (see gemm_persist_kernel).
-inline int xcd_grid_rounds(int ntm, int ntn, int gn, int wgs_per_xcd) {
-    const int gm = 8 / gn;
-    const long long local = (long long)((ntm + gm - 1) / gm) * ((ntn + gn - 1) / gn);
-    return (int)((local + wgs_per_xcd - 1) / wgs_per_xcd);
-}
-// XCD columns: start from the L2 rule (the W slice an L2 must keep, N*K*2/gn bytes, <= 2.5 MiB), then take the gn with
-// the fewest rounds at the expected row count (ties keep the rule's choice). Uneven n splits are fine.
-inline int pick_gn(int M_est, int bm, int N, int bn, int K, int wgs_per_xcd, int* rounds_out) {
-    static int force_gn = getenv("MDR_GEMM_GN") ? atoi(getenv("MDR_GEMM_GN")) : 0;
-    const int ntm = (M_est + bm - 1) / bm, ntn = N / bn;
-    int gn = 1;
-    while (gn < 8 && (size_t)N * K * 2 / gn > (size_t)(5 << 19) && gn * 2 <= ntn) gn *= 2;
-    int best = gn, best_r = xcd_grid_rounds(ntm, ntn, gn, wgs_per_xcd);
-    for (int c = 1; c <= 8 && c <= ntn; c *= 2) {
-        const int r = xcd_grid_rounds(ntm, ntn, c, wgs_per_xcd);
-        if (r < best_r) { best = c; best_r = r; }
-    }
-    if (force_gn == 1 || force_gn == 2 || force_gn == 4 || force_gn == 8) { best = force_gn; best_r = xcd_grid_rounds(ntm, ntn, best, wgs_per_xcd); }
-    if (rounds_out) *rounds_out = best_r;
-    return best;
+// Rounds of tiles the busiest workgroup walks (tiles split evenly over 8 XCDs, then round-robin over an XCD's workgroups).
+inline int persistent_rounds(int M_est, int bm, int N, int bn, int wgs_per_xcd) {
+    const long long T = (long long)((M_est + bm - 1) / bm) * (N / bn);
+    const long long per_xcd = (T + 7) / 8;
+    return (int)((per_xcd + wgs_per_xcd - 1) / wgs_per_xcd);
 }
 
 template <int EPI, typename C>
@@ -1195,9 +1231,10 @@ int launch_gemm_persist(const _Float16* A, int lda, const _Float16* W, const flo
         MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI, C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    const int gn = pick_gn(M_est, C::BM, N, C::BN, K, num_cus / 8, nullptr);
     const int grid = num_cus / 8 * 8;
-    hipLaunchKernelGGL((gemm_persist_kernel<EPI, C>), dim3(grid), dim3(C::THREADS), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, gn);
+    const char* em = getenv("MDR_GEMM_EPI");  // measurement knob: 0 stores after the tile, 1 deferred, 2 deferred + two stores may stay in flight
+    hipLaunchKernelGGL((gemm_persist_kernel<EPI, C>), dim3(grid), dim3(C::THREADS), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo,
+                       em ? atoi(em) : 2);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }
@@ -1205,15 +1242,14 @@ int launch_gemm_persist(const _Float16* A, int lda, const _Float16* W, const flo
 template <int EPI>
 int launch_gemm_big(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
                     int M_est, int num_cus, hipStream_t st) {
-    constexpr int lds = GemmB2::LDS_BYTES + kPersistBiasMax * 4;
+    constexpr int lds = GemmB2::LDS_BYTES + kPersistBiasMax * 4 + 8 * 2048;  // slots + bias + per-wave epilogue scratch
     static bool attr = false;
     if (!attr) {
         MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_big_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    const int gn = pick_gn(M_est, 256, N, 256, K, num_cus / 8, nullptr);
     const int grid = num_cus / 8 * 8;
-    hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(grid), dim3(512), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, gn);
+    hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(grid), dim3(512), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }
@@ -1233,15 +1269,13 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
         if (res_added) *res_added = false;
         else if (EPI == EPI_BIAS_RES_F32) return set_error(MDR_E_STATE, "large-M GEMM with a residual needs the caller to take the residual (res_added)");
         constexpr int E = EPI == EPI_BIAS_RES_F32 ? EPI_BIAS_F32 : EPI;
-        // 256x256 tiles move 1/3 fewer L2->LDS bytes per flop (measured 0.82x the time per unit of work) but quantise worse
-        // over 8 XCDs x 32 workgroups: compare the round counts of the two kernels at the expected row count
-        if (sel == 6 || sel == 0) {
-            int r_big = 0, r_p = 0;
-            if (N % 256 == 0) {
-                pick_gn(M_est, 256, N, 256, K, num_cus / 8, &r_big);
-                pick_gn(M_est, 256, N, 128, K, num_cus / 8, &r_p);
-                if (sel == 6 || r_big * 2 * 0.82 < (double)r_p) return launch_gemm_big<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
-            }
+        // Both kernels are bound by the bytes a CU moves over its L2 path, loads AND stores (~20 B/clk/CU measured; skipping
+        // the stores made the K = 768 GEMMs 25-30 % faster, deferring them did not): cost = rounds x (tile inputs + outputs).
+        if ((sel == 6 || sel == 0) && N % 256 == 0) {
+            const double osz = (E == EPI_BIAS_F32) ? 4.0 : 2.0;
+            const double c_big = persistent_rounds(M_est, 256, N, 256, num_cus / 8) * ((256.0 + 256.0) * K * 2 + 256.0 * 256.0 * osz);
+            const double c_p = persistent_rounds(M_est, 256, N, 128, num_cus / 8) * ((256.0 + 128.0) * K * 2 + 256.0 * 128.0 * osz);
+            if (sel == 6 || c_big < c_p) return launch_gemm_big<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
         }
         return launch_gemm_persist<E, GemmP>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
     }
