@@ -138,6 +138,10 @@ size_t mdr_encoder_workspace_bytes(const mdr_encoder* h, int batch, int seq_len)
 int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* mask_dev, int batch, int seq_len,
                         float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Optional: the fraction of non-pad positions (tokens / (batch * seq_len)) the caller expects in the next forwards, 0 = unknown.
+ * Only steers tile-shape heuristics (the packed token count itself is computed on the device); results do not depend on it. */
+int mdr_encoder_set_fill_hint(mdr_encoder* h, float fill);
+
 /* ------------------------------------------------------------------------------------------------
  * Device-side construction of the hop-2 encoder inputs ==
  *   doc = id2doc[str(doc_id)]["text"]; empty -> title and D[b][j] = -inf     /root/reference/scripts/eval/eval_mhop_retrieval.py:158-166

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "mdr_encoder_workspace_bytes": (_c.c_size_t, [_c.c_void_p, _c.c_int, _c.c_int]),
     "mdr_encoder_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
                                        _c.c_size_t, _c.c_void_p]),
+    "mdr_encoder_set_fill_hint": (_c.c_int, [_c.c_void_p, _c.c_float]),
     "mdr_test_gemm_f16": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int,
                                      _c.c_int, _c.c_int, _c.c_void_p]),
 }

@@ -14,6 +14,7 @@ line for line. The arithmetic is not here: `load_state_dict` hands the fp32 tens
 mdr_encoder_create (csrc/mdr_encoder.hip) and `encode_seq` calls mdr_encoder_forward.
 """
 import ctypes
+import os
 from collections import OrderedDict
 
 import torch
@@ -160,11 +161,18 @@ class _HipRobertaEncoder:
         if ent is None:
             sid, smk = ids.clone(), msk.clone()
             sout = torch.empty((key[0], self.config.hidden_size), dtype=torch.float32, device=self.device)
-            self._forward_into(sid, smk, sout)  # warm-up: sizes the workspace, sets kernel attributes
-            torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._forward_into(sid, smk, sout)
+            # the capture freezes the tile-shape choices: tell the library how full this shape's batches are (the first
+            # batch stands for the later ones of the same shape; only speed depends on it). One sync, at capture time only.
+            fill = float(smk.sum().item()) / float(smk.numel()) if os.environ.get("MDR_FILL_HINT", "1") != "0" else 0.0
+            _lib.check(_lib.lib().mdr_encoder_set_fill_hint(self._h, min(1.0, max(fill, 1e-3)) if fill > 0 else 0.0))
+            try:
+                self._forward_into(sid, smk, sout)  # warm-up: sizes the workspace, sets kernel attributes
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._forward_into(sid, smk, sout)
+            finally:
+                _lib.check(_lib.lib().mdr_encoder_set_fill_hint(self._h, 0.0))
             ent = (graph, sid, smk, sout, self._ws)
             if len(self._graphs) >= 16:  # bounded cache (ragged last batches, corpus encoding with many widths)
                 self._graphs.pop(next(iter(self._graphs)))
