@@ -41,4 +41,6 @@ def encode_args(argv=None):
     p = common_args()
     p.add_argument("--embed_save_path", type=str, default="")
     p.add_argument("--is_query_embed", action="store_true")
+    # addition of this build (off by default): also write <embed_save_path>.bf16.npy, the matrix as bf16 bit patterns
+    p.add_argument("--save_bf16", action="store_true")
     return p.parse_args(argv)

@@ -21,14 +21,18 @@ from .data import EmDataset, em_collate
 from .retriever import RobertaConfig, RobertaCtxEncoder, load_saved, move_to_cuda
 
 
-def predict(model, eval_dataloader, out, row0=0):
-    """reference :95-113 -- batches -> model(batch)['embed'] -> rows of `out` (streamed, not torch.cat'ed)."""
+def predict(model, eval_dataloader, out, row0=0, out_bf16=None):
+    """reference :95-113 -- batches -> model(batch)['embed'] -> rows of `out` (streamed, not torch.cat'ed).
+    out_bf16 (optional): a uint16 matrix receiving the same rows rounded to bf16 (round-to-nearest-even bit patterns)."""
     model.eval()
     at = row0
     for batch in eval_dataloader:
         batch_to_feed = move_to_cuda(batch)
         with torch.no_grad():
-            embed = model(batch_to_feed)["embed"].cpu().numpy()
+            e = model(batch_to_feed)["embed"]
+            embed = e.cpu().numpy()
+            if out_bf16 is not None:
+                out_bf16[at:at + embed.shape[0]] = e.to(torch.bfloat16).view(torch.int16).cpu().numpy().view(np.uint16)
         out[at:at + embed.shape[0]] = embed
         at += embed.shape[0]
     return at - row0
@@ -70,14 +74,21 @@ def main(argv=None, tokenizer=None):
     loader = DataLoader(torch.utils.data.Subset(dataset, range(lo, hi)), batch_size=args.predict_batch_size, collate_fn=em_collate,
                         pin_memory=True, num_workers=args.num_workers)
     path = args.embed_save_path + ".npy"  # np.save appends .npy to the same string that names the id2doc directory (:93)
+    side = args.embed_save_path + ".bf16.npy"
     if rank == 0:
         mm = np.lib.format.open_memmap(path, mode="w+", dtype=np.float32, shape=(n, cfg.hidden_size))
         del mm
+        if args.save_bf16:
+            mm = np.lib.format.open_memmap(side, mode="w+", dtype=np.uint16, shape=(n, cfg.hidden_size))
+            del mm
     if world > 1:
         torch.distributed.barrier()
     out = np.load(path, mmap_mode="r+")
-    predict(model, loader, out, row0=lo)
+    out16 = np.load(side, mmap_mode="r+") if args.save_bf16 else None
+    predict(model, loader, out, row0=lo, out_bf16=out16)
     out.flush()
+    if out16 is not None:
+        out16.flush()
     if world > 1:
         torch.distributed.barrier()
     if rank == 0:

@@ -10,7 +10,9 @@ over the ranks (one RCCL all_gather of per-shard top-k per hop), rank 0 logs and
 Differences from the reference, all deliberate: `--gpu` is implied (there is no CPU
 path) and no device id is hard-coded; `--hnsw` is rejected (approximate search is out of scope);
 `--save-index` is rejected (it wrote a FAISS file to a hard-coded path); the tokenizer is loaded from
-`--model-name` as a LOCAL directory when there is no network.
+`--model-name` as a LOCAL directory when there is no network. Additions (off by default): `--hop2-on-device`
+(token arena + device-side hop-2 assembly), `--index-storage bf16` (+ bf16 sidecar), `--corpus-store`
+(memory-mapped corpus instead of the JSON dict). `--only-eval-ans` is the reference's answer-recall mode.
 """
 import argparse
 import json
@@ -20,7 +22,7 @@ import os
 import numpy as np
 import torch
 
-from . import mhop
+from . import answer_recall, mhop
 from .index import IndexFlatIP, ShardedIndexFlatIP
 from .retriever import RobertaConfig, RobertaRetriever, load_saved, move_to_cuda
 
@@ -48,6 +50,11 @@ def build_parser():
     p.add_argument("--save-path", type=str, default="")
     p.add_argument("--stop-drop", default=0, type=float)
     p.add_argument("--hnsw", action="store_true")
+    # additions of this build (defaults reproduce the reference)
+    p.add_argument("--index-storage", choices=["f32", "bf16"], default="f32",
+                   help="bf16: keep the index rows as bf16 in HBM (2 B/element); reads <index>.bf16.npy when it exists")
+    p.add_argument("--corpus-store", action="store_true",
+                   help="use (build on first use) the memory-mapped <corpus_dict>.store instead of parsing the JSON dict")
     # extension (not in the reference): build the hop-2 inputs on the device from a token arena of the corpus
     # (tokenised once, cached next to the corpus dict) instead of host dict lookups + tokenizer between the hops
     p.add_argument("--hop2-on-device", action="store_true")
@@ -81,24 +88,52 @@ def _tokenize(tokenizer, texts, pairs, max_length):
     return tokenizer(a, b, max_length=max_length, padding="max_length", truncation="longest_first", return_tensors="pt")
 
 
-def load_index(indexpath, d=768):
+def load_corpus(corpus_dict, use_store, rank=0, world=1):
+    """The corpus dict of the reference (:131-135), or its memory-mapped store (built once by rank 0)."""
+    if not use_store:
+        return mhop.load_corpus_dict(corpus_dict)
+    from .corpus_store import build_store
+    store = corpus_dict + ".store"
+    if rank == 0 and (not os.path.exists(store) or os.path.getmtime(store) < os.path.getmtime(corpus_dict)):
+        logger.info("Building the corpus store once...")
+        build_store(corpus_dict, store)
+    if world > 1:
+        torch.distributed.barrier()
+    return mhop.load_corpus_dict(store)
+
+
+def bf16_sidecar_path(indexpath):
+    """`<name>.bf16.npy` next to `<name>.npy`: the same matrix as uint16 bf16 bit patterns (encode_corpus --save_bf16)."""
+    return (indexpath[:-4] if indexpath.endswith(".npy") else indexpath) + ".bf16.npy"
+
+
+def load_index(indexpath, d=768, storage="f32"):
     """`xb = np.load(indexpath).astype('float32'); index = IndexFlatIP(d); index.add(xb)` (reference :94,121-122)
     without the two 16 GB host copies: the .npy is memory-mapped and uploaded in chunks, each rank taking
-    only its own rows."""
-    xb = np.load(indexpath, mmap_mode="r")
+    only its own rows. storage="bf16": rows are kept as bf16 in HBM (2 B/element); when a bf16 sidecar of the matrix
+    exists it is read instead of the fp32 file (half the disk and PCIe bytes, identical index contents)."""
+    side = bf16_sidecar_path(indexpath)
+    use_side = storage == "bf16" and os.path.exists(side)
+    xb = np.load(side if use_side else indexpath, mmap_mode="r")
     n = xb.shape[0]
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-        index = ShardedIndexFlatIP(d, n)
-        index.local.reserve(index.hi - index.lo)
-        step = 1 << 18
-        for lo in range(index.lo, index.hi, step):
-            index.add_local(np.ascontiguousarray(xb[lo:min(index.hi, lo + step)]))
-        return index
-    index = IndexFlatIP(d)
-    index.reserve(n)
+
+    def chunk(lo, hi):
+        if use_side:  # copy out of the read-only map: torch wants a writable buffer
+            return torch.from_numpy(np.array(xb[lo:hi]).view(np.int16)).view(torch.bfloat16)
+        return np.ascontiguousarray(xb[lo:hi])
+
+    kw = {"storage": "bf16"} if storage == "bf16" else {}
     step = 1 << 18
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        index = ShardedIndexFlatIP(d, n, local_index=IndexFlatIP(d, **kw))
+        index.local.reserve(index.hi - index.lo)
+        for lo in range(index.lo, index.hi, step):
+            index.add_local(chunk(lo, min(index.hi, lo + step)))
+        return index
+    index = IndexFlatIP(d, **kw)
+    index.reserve(n)
     for lo in range(0, n, step):
-        index.add(np.ascontiguousarray(xb[lo:lo + step]))
+        index.add(chunk(lo, min(n, lo + step)))
     return index
 
 
@@ -116,12 +151,12 @@ def main(argv=None, tokenizer=None):
         raise SystemExit("--hnsw (approximate HNSW search) is not implemented: this build is the exact flat-IP path only")
     if args.save_index:
         raise SystemExit("--save-index wrote a FAISS file to a hard-coded path in the reference; not supported here")
-    if args.only_eval_ans:
-        raise SystemExit("--only-eval-ans (answer-string recall, CPU regex tokenizer) is not part of the retrieval hot path yet")
 
     logger.info("Loading data...")
     with open(args.raw_data) as f:
         ds_items = [json.loads(line) for line in f.readlines()]
+    if args.only_eval_ans:  # eval_mhop_retrieval.py:76-77: yes/no questions cannot be matched against passage text
+        ds_items = [it for it in ds_items if it["answer"][0] not in ["yes", "no"]]
 
     logger.info("Loading trained model...")
     bert_config = _load_config(args.model_name)
@@ -134,10 +169,10 @@ def main(argv=None, tokenizer=None):
     model.eval()
 
     logger.info("Building index...")
-    index = load_index(args.indexpath, d=bert_config.hidden_size)
+    index = load_index(args.indexpath, d=bert_config.hidden_size, storage=args.index_storage)
 
     logger.info("Loading corpus...")
-    id2doc = mhop.load_corpus_dict(args.corpus_dict)
+    id2doc = load_corpus(args.corpus_dict, args.corpus_store, rank, world)
     logger.info(f"Corpus size {len(id2doc)}")
 
     arena = None
@@ -180,6 +215,9 @@ def main(argv=None, tokenizer=None):
 
             chains = mhop.rank_paths(D, I, D_, I_, args.beam_size, args.topk)
             for ann, ch in zip(batch_ann, chains):
+                if args.only_eval_ans:  # answer-string recall over the retrieved chains; nothing is saved (:208-217)
+                    metrics.append(answer_recall.answer_metrics(ann, ch, id2doc))
+                    continue
                 m = mhop.question_metrics(ch, ann["sp"], id2doc)
                 m.update(question=ann["question"], type=ann["type"])
                 metrics.append(m)
@@ -190,7 +228,7 @@ def main(argv=None, tokenizer=None):
             for rec in retrieval_outputs:
                 out.write(json.dumps(rec) + "\n")
 
-    for line in mhop.summary_lines(metrics):
+    for line in (answer_recall.answer_summary_lines(metrics) if args.only_eval_ans else mhop.summary_lines(metrics)):
         logger.info(line)
     return metrics, retrieval_outputs
 

@@ -25,6 +25,9 @@ def load_corpus_dict(path_or_obj):
     normalised (eval_mhop_retrieval.py:131-133)."""
     id2doc = path_or_obj
     if isinstance(path_or_obj, str):
+        if path_or_obj.endswith(".store"):  # memory-mapped offset-table form of the same data (corpus_store.py)
+            from .corpus_store import CorpusStore
+            return CorpusStore(path_or_obj)
         with open(path_or_obj) as f:
             id2doc = json.load(f)
     if len(id2doc) and isinstance(next(iter(id2doc.values())), list):
@@ -50,20 +53,21 @@ def build_hop2_pairs(batch_q, D, I, id2doc, roberta=True):
     return pairs
 
 
-def rank_paths(D, I, D2, I2, beam, topk):
-    """Best `topk` (hop-1 id, hop-2 id, score) chains per question (eval_mhop_retrieval.py:181-206).
-    Path score = hop-1 score + hop-2 score. Raises IndexError when topk > beam*beam, like the
-    reference. Among equal path scores the reference's order is unspecified (reversed unstable
-    argsort); here it is the same numpy expression so results coincide on every input."""
+def rank_paths(D, I, D2, I2, beam, topk, beam2=None):
+    """Best `topk` (hop-1 id, hop-2 id, score) chains per question (eval_mhop_retrieval.py:181-206; with separate hop
+    widths `beam` x `beam2`, eval_mhop_fever.py:111-130). Path score = hop-1 score + hop-2 score. Raises IndexError when
+    topk > beam*beam2, like the reference. Among equal path scores the reference's order is unspecified (reversed
+    unstable argsort); here it is the same numpy expression so results coincide on every input."""
     B = D.shape[0]
-    if topk > beam * beam:
-        raise IndexError(f"topk={topk} exceeds beam*beam={beam * beam}")
-    scores = (np.asarray(D)[:, :, None] + np.asarray(D2).reshape(B, beam, beam)).reshape(B, beam * beam)
-    I2 = np.asarray(I2).reshape(B, beam, beam)
+    beam2 = beam if beam2 is None else beam2
+    if topk > beam * beam2:
+        raise IndexError(f"topk={topk} exceeds beam*beam2={beam * beam2}")
+    scores = (np.asarray(D)[:, :, None] + np.asarray(D2).reshape(B, beam, beam2)).reshape(B, beam * beam2)
+    I2 = np.asarray(I2).reshape(B, beam, beam2)
     order = np.argsort(scores, axis=1)[:, ::-1][:, :topk]
     out = []
     for b in range(B):
-        i, j = np.divmod(order[b], beam)
+        i, j = np.divmod(order[b], beam2)
         out.append([(int(I[b, ii]), int(I2[b, ii, jj]), float(scores[b, o])) for ii, jj, o in zip(i, j, order[b])])
     return out
 

@@ -228,6 +228,56 @@ def gen_mhop():
         json.dump({"id2doc_list": id2doc_list, "items": items, "cases": cases}, f, indent=1)
 
 
+def gen_answer_recall():
+    """Outputs of the reference's own para_has_answer / SimpleTokenizer (mdr/retrieval/utils/utils.py:126-139,
+    basic_tokenizer.py:238-277) and of the literal concatenation + log expressions of eval_mhop_retrieval.py:208-217,269-273
+    (inline under __main__, restated here) on hand-made paragraphs: unicode forms, punctuation, case, token boundaries."""
+    from mdr.retrieval.utils.basic_tokenizer import SimpleTokenizer
+    from mdr.retrieval.utils.utils import para_has_answer
+    tok = SimpleTokenizer()
+    paras = [
+        "Barack Obama was born in Honolulu, Hawaii (U.S.A.) on August 4, 1961.",
+        "The caf\u00e9 Fran\u00e7ois opened in 1999; it's \u201cfamous\u201d for cr\u00e8me br\u00fbl\u00e9e.",
+        "cafe\u0301 with a combining accent; na\u00efve co-operate re\u2011enter state-of-the-art 3.14 1,000 $5 #tag @me",
+        "\u6771\u4eac\u90fd is Tokyo.\tTabs\nand newlines\u00a0and nbsp \u200b zero width. \u0130stanbul STRASSE stra\u00dfe",
+        "",
+        "yes no Alpha alpha textBeta beta text",
+    ]
+    answers = [["Honolulu"], ["honolulu , hawaii"], ["Hawaii U.S.A"], ["u . s . a ."], ["August 4 1961"], ["August 4, 1961"], ["4,"],
+               ["Cafe Francois"], ["caf\u00e9 fran\u00e7ois"], ["cafe\u0301"], ["caf\u00e9"], ["it s"], ["it's"], ["\u201cfamous\u201d"], ["famous"],
+               ["creme brulee"], ["cr\u00e8me br\u00fbl\u00e9e"], ["naive"], ["na\u00efve"], ["co operate"], ["co-operate"], ["re enter"],
+               ["state of the art"], ["3.14"], ["3 . 14"], ["1,000"], ["1000"], ["$ 5"], ["# tag"], ["\u6771\u4eac\u90fd"], ["\u6771\u4eac"],
+               ["Tokyo Tabs"], ["tabs and"], ["and nbsp zero"], ["nbsp zero width"], ["istanbul"], ["\u0130stanbul"], ["strasse"],
+               ["stra\u00dfe"], ["STRASSE stra\u00dfe"], [""], ["   "], ["yes"], ["textbeta"], ["text beta"], ["alpha text", "nothing"],
+               ["nothing", "beta text"], ["nothing at all"]]
+    tokens = [tok.tokenize(__import__("unicodedata").normalize("NFD", p)).words(uncased=True) for p in paras]
+    table = [[bool(para_has_answer(a, p, tok)) for a in answers] for p in paras]
+    # the inline CLI expressions (eval_mhop_retrieval.py:209-217 and :269-273)
+    id2doc = {"0": {"title": "Alpha", "text": "alpha text"}, "1": {"title": "Beta", "text": "beta text"},
+              "2": {"title": "Gamma", "text": ""}, "3": {"title": "Delta", "text": "delta \u00e9t\u00e9 1999"}}
+    items = [{"question": "q0?", "answer": ["beta text"], "type": "bridge"}, {"question": "q1", "answer": ["ete 1999", "\u00e9t\u00e9 1999"]},
+             {"question": "q2", "answer": ["textBeta"], "type": "bridge"}, {"question": "q3", "answer": ["missing"], "type": "comparison"}]
+    chains = [[("0", "1")], [("2", "3"), ("0", "0")], [("0", "1"), ("1", "0")], [("3", "2")]]
+    concat, metrics = [], []
+    for it, paths in zip(items, chains):
+        concat_p = "yes no "
+        for p in paths:
+            concat_p += " ".join([id2doc[doc_id]["title"] + " " + id2doc[doc_id]["text"] for doc_id in p])
+        concat.append(concat_p)
+        metrics.append({"question": it["question"], "ans_recall": int(para_has_answer(it["answer"], concat_p, tok)), "type": it.get("type", "single")})
+    import collections
+    type2items = collections.defaultdict(list)
+    for m in metrics:
+        type2items[m["type"]].append(m)
+    log = [f"Evaluating {len(metrics)} samples...", f'Ans Recall: {np.mean([m["ans_recall"] for m in metrics])}']
+    for t in type2items.keys():
+        log.append(f"{t} Questions num: {len(type2items[t])}")
+        log.append(f'Ans Recall: {np.mean([m["ans_recall"] for m in type2items[t]])}')
+    with open(os.path.join(GOLD, "answer_recall.json"), "w") as f:
+        json.dump({"paras": paras, "answers": answers, "tokens": tokens, "has_answer": table, "id2doc": id2doc, "items": items,
+                   "chains": [[list(p) for p in c] for c in chains], "concat": concat, "metrics": metrics, "log": log}, f, indent=1)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     only = set(sys.argv[1:])
@@ -238,6 +288,8 @@ if __name__ == "__main__":
             gen_mhop()
         if not only or "collate" in only:
             gen_collate()
+        if not only or "answer_recall" in only:
+            gen_answer_recall()
         if not only or "load_saved" in only:
             gen_load_saved(tmp)
         if not only or "encoder" in only:

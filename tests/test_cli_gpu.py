@@ -66,9 +66,11 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys):
     save = tmp_path / "emb"
     path = encode_corpus.main(["--do_predict", "--predict_batch_size", "50", "--model_name", str(cfg_dir), "--predict_file", str(corpus),
                                "--init_checkpoint", str(ckpt), "--embed_save_path", str(save), "--fp16", "--max_c_len", "30",
-                               "--num_workers", "0"], tokenizer=tok)
+                               "--num_workers", "0", "--save_bf16"], tokenizer=tok)
     xb = np.load(path)
     assert xb.shape == (257, 768) and xb.dtype == np.float32
+    side = np.load(str(save) + ".bf16.npy")  # bf16 sidecar: RNE bit patterns of the same matrix
+    assert side.dtype == np.uint16 and np.array_equal(side, torch.from_numpy(xb).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16))
     id2doc = json.load(open(save / "id2doc.json"))
     assert id2doc["5"] == ["T5", "  ", False] and len(id2doc) == 257
     # passage 7 against the numpy restatement of the encoder
@@ -99,6 +101,48 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys):
     for needle in ("Loading data...", "Building index...", "Corpus size 257", "Evaluating 23 samples...", "\tAvg PR:", "\tAvg P-EM:",
                    "\tAvg 1-Recall:", "\tPath Recall:", "bridge Questions num: 11", "comparison Questions num: 12"):
         assert needle in err, needle
+    # bf16 index from the sidecar + memory-mapped corpus store: same chains unless bf16 rounding swaps a near-tie
+    out5 = tmp_path / "paths_bf16.jsonl"
+    metrics5, recs5 = eval_mhop_retrieval.main([str(data), path, str(save / "id2doc.json"), str(ckpt), "--batch-size", "10", "--beam-size", "3",
+                                                "--topk", "4", "--model-name", str(cfg_dir), "--gpu", "--save-path", str(out5), "--max-q-len", "12",
+                                                "--max-q-sp-len", "40", "--index-storage", "bf16", "--corpus-store"], tokenizer=tok)
+    assert (save / "id2doc.json.store").exists() and len(recs5) == 23
+    same = sum(a == b for a, b in zip(out5.read_text().strip().split("\n"), lines))
+    assert same >= 20, same
+    # --only-eval-ans: yes/no questions are dropped, answer-string recall over the retrieved chains, nothing is saved
+    qa = [dict(q, answer=(["yes"] if i % 5 == 0 else [docs[(i * 7) % 257]["text"].split()[0] if i % 2 else "zzz-not-there"]))
+          for i, q in enumerate(qs)]
+    data_a = tmp_path / "qas_ans.json"
+    data_a.write_text("\n".join(json.dumps(q) for q in qa))
+    out3 = tmp_path / "paths_ans.jsonl"
+    capsys.readouterr()
+    m3, r3 = eval_mhop_retrieval.main([str(data_a), path, str(save / "id2doc.json"), str(ckpt), "--batch-size", "10", "--beam-size", "3",
+                                       "--topk", "4", "--model-name", str(cfg_dir), "--gpu", "--save-path", str(out3), "--max-q-len", "12",
+                                       "--max-q-sp-len", "40", "--only-eval-ans"], tokenizer=tok)
+    kept = [q for q in qa if q["answer"][0] != "yes"]
+    assert len(m3) == len(kept) == 18 and r3 == [] and out3.read_text() == ""
+    assert set(m3[0].keys()) == {"question", "ans_recall", "type"} and all(m["ans_recall"] in (0, 1) for m in m3)
+    assert all(m["ans_recall"] == 0 for m, q in zip(m3, kept) if q["answer"] == ["zzz-not-there"])
+    err3 = capsys.readouterr().err
+    assert "Evaluating 18 samples..." in err3 and "Ans Recall: " in err3 and "Avg P-EM" not in err3
+    # FEVER drop-in: separate beam widths, list-valued corpus dict, (title, text) chains; hop-1 ids equal the HotpotQA CLI's
+    claims = [{"id": i, "claim": q["question"][:-1], "label": "SUPPORTS"} for i, q in enumerate(qs[:7])]
+    data_f = tmp_path / "claims.json"
+    data_f.write_text("\n".join(json.dumps(c) for c in claims))
+    out4 = tmp_path / "sub" / "fever.jsonl"
+    from multihop_dense_retrieval_amd import eval_mhop_fever
+    recs4 = eval_mhop_fever.main([str(data_f), path, str(save / "id2doc.json"), str(ckpt), "--batch-size", "4", "--beam-size-1", "2",
+                                  "--beam-size-2", "5", "--topk", "6", "--model-name", str(cfg_dir), "--gpu", "--save-path", str(out4),
+                                  "--max-q-len", "12", "--max-q-sp-len", "40"], tokenizer=tok)
+    lines4 = out4.read_text().strip().split("\n")
+    assert len(lines4) == 7 and len(recs4) == 7
+    r0 = json.loads(lines4[0])
+    assert list(r0.keys()) == ["id", "claim", "candidate_chains"] and len(r0["candidate_chains"]) == 6
+    assert all(len(c) == 2 and len(c[0]) == 2 for c in r0["candidate_chains"])
+    hop1_fever = {c[0][0] for c in r0["candidate_chains"]}
+    assert len(hop1_fever) <= 2  # beam-size-1 = 2
+    with pytest.raises(SystemExit):
+        eval_mhop_fever.main([str(data_f), path, str(save / "id2doc.json"), str(ckpt), "--model-name", "bert-base-uncased"], tokenizer=tok)
     # hop-1 decision of question 0 equals an oracle recomputation from the saved index
     enc = tok(qs[0]["question"][:-1], max_length=12, padding="max_length")
     qv = roberta_oracle.encode(sd, geom, enc["input_ids"].numpy(), enc["attention_mask"].numpy(), np.float64)

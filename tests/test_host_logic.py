@@ -108,3 +108,79 @@ def test_em_dataset_writes_id2doc_and_pairs_title_text(tmp_path):
     assert ds[1]["input_ids"].tolist() == [[0, 8, 2, 2, 8, 2]]  # title used as text
     b = data.em_collate([ds[0], ds[2]])
     assert b["input_ids"].shape == (2, 6) and b["input_mask"].sum().item() == 6 + ds[2]["input_ids"].shape[1]
+
+
+def test_answer_recall_matches_reference_functions(golden):
+    """--only-eval-ans: SimpleTokenizer words, para_has_answer, the chain concatenation (no separator between chains) and
+    the log lines, against outputs of the reference's own functions (tests/golden/answer_recall.json)."""
+    import unicodedata
+
+    from multihop_dense_retrieval_amd import answer_recall as ar
+    g = golden("answer_recall.json")
+    for para, toks in zip(g["paras"], g["tokens"]):
+        assert ar.simple_words(unicodedata.normalize("NFD", para)) == toks
+    for i, para in enumerate(g["paras"]):
+        for j, ans in enumerate(g["answers"]):
+            assert ar.para_has_answer(ans, para) == g["has_answer"][i][j], (para, ans)
+    metrics = []
+    for it, chains, concat, want in zip(g["items"], g["chains"], g["concat"], g["metrics"]):
+        ch = [(int(a), int(b), 0.0) for a, b in chains]
+        assert ar.chain_text(ch, g["id2doc"]) == concat
+        m = ar.answer_metrics(it, ch, g["id2doc"])
+        assert m == want
+        metrics.append(m)
+    assert ar.answer_summary_lines(metrics) == g["log"]
+    with pytest.raises(AssertionError):
+        ar.para_has_answer("not a list", "text")
+
+
+def test_rank_paths_with_separate_beam_widths_matches_the_fever_expression():
+    """eval_mhop_fever.py:130-150: D_ reshaped to [B, beam1, beam2], path = D[:, :, None] + D_, reversed argsort of the
+    ravel, unravel over (beam1, beam2) -- restated literally here (the script cannot be imported: top-level faiss/apex)."""
+    rng = np.random.default_rng(9)
+    B, b1, b2, topk = 4, 2, 5, 7
+    D = -np.sort(-rng.standard_normal((B, b1)).astype(np.float32), axis=1)
+    D[1, 1] = -np.inf
+    I = rng.integers(0, 50, (B, b1)).astype(np.int64)
+    D2 = -np.sort(-rng.standard_normal((B * b1, b2)).astype(np.float32), axis=1)
+    I2 = rng.integers(0, 50, (B * b1, b2)).astype(np.int64)
+    got = mhop.rank_paths(D, I, D2, I2, b1, topk, beam2=b2)
+    D_, I_ = D2.reshape(B, b1, b2), I2.reshape(B, b1, b2)
+    path_scores = np.expand_dims(D, axis=2) + D_
+    for idx in range(B):
+        ranked = np.vstack(np.unravel_index(np.argsort(path_scores[idx].ravel())[::-1], (b1, b2))).transpose()
+        want = [(int(I[idx, p[0]]), int(I_[idx, p[0], p[1]])) for p in ranked[:topk]]
+        assert [(h1, h2) for h1, h2, _ in got[idx]] == want
+    with pytest.raises(IndexError):
+        mhop.rank_paths(D, I, D2, I2, b1, b1 * b2 + 1, beam2=b2)
+
+
+def test_fever_record_looks_text_up_by_title():
+    from multihop_dense_retrieval_amd import eval_mhop_fever as fv
+    id2doc = {"0": ["A", "first a", True], "1": ["B", "b text", False], "2": ["A", "second a", False]}
+    title2doc = {item[0]: item[1] for item in id2doc.values()}  # later duplicates win, like the reference (:80)
+    rec = fv.fever_record({"id": 7, "claim": "c", "label": "x"}, [(0, 1, 0.5), (2, 0, 0.1)], id2doc, title2doc)
+    assert list(rec.keys()) == ["id", "claim", "candidate_chains"]
+    assert json.loads(json.dumps(rec))["candidate_chains"] == [[["A", "second a"], ["B", "b text"]], [["A", "second a"], ["A", "second a"]]]
+    a = fv.build_parser().parse_args(["d", "i", "c", "m"])
+    assert (a.topk, a.max_q_len, a.max_q_sp_len, a.beam_size_1, a.beam_size_2, a.batch_size, a.model_name) == (2, 45, 400, 5, 5, 100, "bert-base-uncased")
+
+
+def test_corpus_store_round_trips_the_corpus_dict(tmp_path):
+    """The memory-mapped store answers like the parsed JSON dict: same keys, same {"title","text"} values, both the dict and
+    the [title, text, intro] list forms, unicode, empty texts; json.dumps of an entry is what the reference would write."""
+    from multihop_dense_retrieval_amd import corpus_store
+    docs = {str(i): {"title": f"T{i} \u00e9", "text": ("" if i == 3 else f"text {i} \u6771\u4eac " * (i % 4))} for i in range(37)}
+    src = tmp_path / "id2doc.json"
+    src.write_text(json.dumps(docs))
+    st = corpus_store.CorpusStore(corpus_store.build_store(str(src), str(tmp_path / "id2doc.json.store")))
+    assert len(st) == 37 and list(st)[:3] == ["0", "1", "2"] and "36" in st and "37" not in st and "x" not in st and "07" not in st
+    for k, v in docs.items():
+        assert st[k] == v and json.dumps(st[k]) == json.dumps(v)
+    assert mhop.load_corpus_dict(str(tmp_path / "id2doc.json.store"))["5"]["title"] == docs["5"]["title"]
+    lists = {str(i): [f"t{i}", f"x{i}", i % 2 == 0] for i in range(5)}
+    st2 = corpus_store.CorpusStore(corpus_store.build_store(lists, str(tmp_path / "l.store")))
+    assert st2.as_list("2") == ["t2", "x2", True] and st2["1"] == {"title": "t1", "text": "x1", "intro": False}
+    assert {v["title"]: v["text"] for v in st2.values()} == {f"t{i}": f"x{i}" for i in range(5)}
+    with pytest.raises(ValueError):
+        corpus_store.build_store({"0": ["a", "b"], "2": ["c", "d"]}, str(tmp_path / "bad.store"))
