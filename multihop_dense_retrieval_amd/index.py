@@ -204,9 +204,10 @@ class ShardedIndexFlatIP:
         D, I = self.local.search(q, k)
         return self.search_gathered(D, I)
 
-    def search_gathered(self, D, I):
-        """Exchange this rank's (D, I) [nq, k] with every other rank and merge; identical on all ranks."""
-        if self.world == 1:
+    def search_gathered(self, D, I, force=False):
+        """Exchange this rank's (D, I) [nq, k] with every other rank and merge; identical on all ranks.
+        force: run the collective and the merge even in a one-rank group (self-test of the RCCL path on a 1-GPU box)."""
+        if self.world == 1 and not (force and self.dist.is_initialized()):
             return D, I
         as_numpy = isinstance(D, np.ndarray)
         Dt = torch.from_numpy(D) if as_numpy else D
