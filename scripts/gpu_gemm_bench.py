@@ -19,7 +19,11 @@ for name, N, K, epi in (("qkv", 2304, 768, 0), ("out", 768, 768, 3), ("ffn1", 30
     W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).half()
     b = torch.randn((N,), generator=g, device="cuda")
     out = torch.empty((M, N), device="cuda", dtype=torch.float32)  # large enough for every epilogue
-    for kern in kernels:
+    # SWEEP_ENV=NAME SWEEP_VALUES=a,b,c: re-time every kernel with the library's measurement knob NAME set to each value
+    sweep = [(os.environ["SWEEP_ENV"], v) for v in os.environ.get("SWEEP_VALUES", "").split(",")] if os.environ.get("SWEEP_ENV") else [None]
+    for kern, knob in [(k, w) for k in kernels for w in sweep]:
+        if knob is not None:
+            os.environ[knob[0]] = knob[1]
         for _ in range(3):
             _lib.check(L.mdr_test_gemm_f16(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, None, N, K, out.data_ptr(), epi, kern, 0, st))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,4 +33,4 @@ for name, N, K, epi in (("qkv", 2304, 768, 0), ("out", 768, 768, 3), ("ffn1", 30
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
-        print(f"{name:5s} M={M} N={N} K={K} kernel {kern}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
+        print(f"{name:5s} M={M} N={N} K={K} kernel {kern}{'' if knob is None else ' ' + knob[0] + '=' + knob[1]}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
