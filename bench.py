@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--topk", type=int, default=1)
     ap.add_argument("--max-q-len", type=int, default=70)
     ap.add_argument("--max-q-sp-len", type=int, default=350)
+    ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
+                    help="index storage: f32 = fp32-accurate fp16 (hi, lo) pairs (the headline), bf16 = rows rounded to bf16 (BASELINE configs[4])")
     ap.add_argument("--no-encoder", action="store_true", help="MIPS-only step (query embeddings synthetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
@@ -116,13 +118,14 @@ def main():
     from multihop_dense_retrieval_amd import mhop
 
     N, d, B = args.rows, args.dim, args.batch
+    skw = {"storage": "bf16"} if args.storage == "bf16" else {}
     t0 = time.time()
     if world > 1:
-        sidx = mdr_index.ShardedIndexFlatIP(d, N)
+        sidx = mdr_index.ShardedIndexFlatIP(d, N, local_index=mdr_index.IndexFlatIP(d, device=device, **skw))
         lo, hi = sidx.lo, sidx.hi
         local = sidx.local
     else:
-        local = mdr_index.IndexFlatIP(d, device=device)
+        local = mdr_index.IndexFlatIP(d, device=device, **skw)
         sidx = local
         lo, hi = 0, N
     local.reserve(hi - lo)
@@ -179,21 +182,22 @@ def main():
     traffic, traffic_src = args.pmc_traffic, "--pmc-traffic"
     if traffic is None:
         for name, (ratio, src) in PMC_TRAFFIC_RATIO.items():
-            if name in local.last_kernel() and d == 768:
+            if name in local.last_kernel() and d == 768 and args.storage != "bf16":
                 traffic, traffic_src = float(round(stream_bytes * ratio)), f"{src} (measured ratio {ratio} x algorithmic bytes)"
     roofline = {"bound": "hbm", "kernel": local.last_kernel(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
                 "algorithmic_bytes_per_launch": stream_bytes,
-                "designed_hbm_bytes_per_launch": stream_bytes // 2 if "screen" in local.last_kernel() else stream_bytes, "avg_launch_ms": round(search_ms, 4),
+                "designed_hbm_bytes_per_launch": stream_bytes // 2 if ("screen" in local.last_kernel() and args.storage != "bf16") else stream_bytes, "avg_launch_ms": round(search_ms, 4),
                 "launches_timed": pipe.search_calls_timed(), "corpus_passes_per_launch": passes}
 
     result = {
         "metric": "queries/sec (2-hop, beam-size x topk) over 5Mx768 index",
         "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
-        "dtype": "f32 (index stored as fp16 hi/lo pairs, fp32 accumulate); encoder f16 MFMA / f32 accumulate",
+        "dtype": ("bf16 index rows, fp32 accumulate" if args.storage == "bf16" else "f32 (index stored as fp16 hi/lo pairs, fp32 accumulate)")
+                 + "; encoder f16 MFMA / f32 accumulate",
         "data": "synthetic",
-        "config": {"workload": f"synthetic {N}x{d} fp32 corpus{' row-sharded over ' + str(world) + ' GPUs' if world > 1 else ''}, "
+        "config": {"workload": f"synthetic {N}x{d} {'bf16' if args.storage == 'bf16' else 'fp32'} corpus{' row-sharded over ' + str(world) + ' GPUs' if world > 1 else ''}, "
                                f"{B}-question batches{' per GPU (global batch ' + str(GB) + ')' if weak else ''}, 2-hop beam={args.beam} topk={args.topk}"
                                f"{' , MIPS-only (no encoder)' if not pipe.use_encoder else ', RoBERTa-base encoder (random init)'}",
                    "rows": N, "dim": d, "batch": B, "global_batch": GB, "beam": args.beam, "topk": args.topk, "shards": world,
