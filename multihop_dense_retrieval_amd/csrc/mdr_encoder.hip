@@ -917,7 +917,7 @@ __global__ void __launch_bounds__(512) attention_kernel(const _Float16* __restri
             if (t < nt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f((s[t][r] - mx) * 1.4426950408889634f);
+                    const float e = __builtin_amdgcn_exp2f((s[t][r] - mx) * 1.4426950408889634f);  // argument <= 0: raw v_exp_f32
                     s[t][r] = e;
                     sum += e;
                 }
@@ -1049,25 +1049,29 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], acc, 0, 0, 0);
+                acc *= 0.125f;
+                if (t == nt - 1) {  // only the chunk's last tile can hold keys past the sequence (clamped copies of its last row)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kc0 + t * 16 + 4 * g + r;
-                    s[t][r] = key < len ? acc[r] * 0.125f : -INFINITY;
-                    cmax = fmaxf(cmax, s[t][r]);
+                    for (int r = 0; r < 4; ++r)
+                        if (kc0 + t * 16 + 4 * g + r >= len) acc[r] = -INFINITY;
                 }
+                s[t] = acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, acc[r]);
             }
         }
         cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
         const float m_new = fmaxf(m_run, cmax);  // finite: every chunk holds at least one valid key
         const float alpha = exp2f((m_run - m_new) * 1.4426950408889634f);  // 0 on the first chunk
+        const float mb = -m_new * 1.4426950408889634f;
         float csum = 0.f;
 #pragma unroll
         for (int t = 0; t < NTC; ++t)
             if (t < nt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f((s[t][r] - m_new) * 1.4426950408889634f);
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], 1.4426950408889634f, mb));  // argument <= 0 (up to rounding): raw v_exp_f32
                     s[t][r] = e;
                     csum += e;
                 }
