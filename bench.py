@@ -14,9 +14,15 @@ N > 1   : launched by torch.distributed.run, one rank per GPU. The 5M-row corpus
           own questions. Per-GPU work is then constant in N (100 sequences through the encoder; rows/N x queries*N
           through the MIPS). --scaling strong keeps ONE 100-question batch and splits the encoder slices instead; a
           10 ms step of 2 x 12 dependent transformer layers is latency-bound there.
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the MIPS screen kernel mips_screen_kernel<24,1,0>,
-HBM-bound; time = HIP events around every search call on the launch stream) and `cpu_baseline`
-(oracle/flat_ip_oracle.c, the FAISS-equivalent CPU path, on a bounded row sample).
+Prints ONE JSON line on rank 0 with
+  roofline          the MIPS kernel (HBM-bound): PHYSICAL HBM bytes per search call / HIP-event time of the call on the launch
+                    stream / 8 TB/s. The screen kernels stream only the fp16 hi plane of the fp32-accurate index, so the
+                    fp32-equivalent ("algorithmic", SURVEY.md §8d: N x d x 4 bytes) rate is a SEPARATE key, never `frac`.
+  roofline_encoder  the encoder (MFMA-bound, the larger share of the step): executed FLOPs / stage time / 2.5 PFLOP/s.
+  self_check        structural properties + `full_size_exact`: after the timed region every row of the 5M corpus is
+                    re-scored with a plain torch matmul and compared with what the kernels returned.
+  cpu_baseline      the FAISS-equivalent CPU path on a bounded row sample (N = 1 only).
+  strong_scaling    (N > 1, default weak scaling) the same job with ONE --batch questions for all ranks.
 
 roofline.traffic is HBM bytes per search call from a separate `rocprofv3 --pmc FETCH_SIZE` pass (scripts/gpu_pmc_screen.sh;
 KB x 1024 x 2, the gfx950 correction of MI355X_MICROARCH.md), which cannot run inside this process: the measured ratio
@@ -36,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense fp16/bf16 MFMA peak
 CHUNK_ROWS = 250_000
 
 # measured HBM fetch bytes per search call / algorithmic bytes (N_pad * d * 4), from rocprofv3 --pmc FETCH_SIZE passes
@@ -69,6 +76,8 @@ def parse():
                          "row-sharded index; strong = one batch of --batch questions, encoder slices split over ranks")
     ap.add_argument("--share-gpu", action="store_true", help="debug: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--pmc-traffic", type=float, default=None, help="HBM bytes per launch from a rocprofv3 --pmc pass")
+    ap.add_argument("--no-verify", action="store_true", help="skip the full-size brute-force exactness check after the timed region")
+    ap.add_argument("--no-strong", action="store_true", help="N>1, weak scaling: do not append the strong-scaling sub-result")
     return ap.parse_args()
 
 
@@ -93,6 +102,124 @@ def build_shard(index, lo, hi, dim, device, keep_rows=None):
     return kept
 
 
+def encoder_flops(lens, L_pad, layers=12, H=768, F=3072):
+    """(executed, padded-equivalent) FLOPs of one encoder call. `lens` = real token count per sequence.
+    Executed: masked tokens are dropped, and the LAST layer is evaluated for the CLS rows only after its K/V projection
+    (one query per head). Padded-equivalent: what the reference computes -- every layer on all B x L_pad positions."""
+    lens = np.asarray(lens, np.float64)
+    B, T = len(lens), float(lens.sum())
+    per_tok_full = 2.0 * (3 * H * H + H * H + 2 * H * F)            # QKV + out-proj + FFN1 + FFN2 per token per layer
+    attn_full = 4.0 * H * float((lens ** 2).sum())                   # QK^T + PV over all heads, per layer
+    executed = (layers - 1) * (T * per_tok_full + attn_full)
+    executed += T * 2.0 * 3 * H * H                                  # last layer: K/V (and Q) projection of every token
+    executed += 4.0 * H * T                                          # ... one query per (sequence, head)
+    executed += B * 2.0 * (H * H + 2 * H * F)                        # ... out-proj + FFN on the CLS rows
+    executed += B * 2.0 * H * H                                      # project.0
+    padded = layers * (B * L_pad * per_tok_full + B * 4.0 * H * L_pad * L_pad) + B * 2.0 * H * H
+    return executed, padded
+
+
+def verify_full_size(out, lo, hi, n_total, d, device, beam):
+    """Exactness at FULL size, outside the timed region: re-generate this rank's rows chunk by chunk, score ALL of them
+    against the hop-1 and hop-2 query embeddings of the last timed step with a plain fp32 matmul (torch / rocBLAS: an
+    independent implementation), keep the running top-`beam`, and compare with what the MIPS kernels returned:
+      * every returned score equals the fp64 inner product of its query with the returned row (|diff| <= 1e-3, the
+        north star's fp32 bar) -- checked for the rows of this shard;
+      * no row of the shard beats the returned k-th score by more than the fp32-matmul noise (2e-3);
+      * ids agree with the brute-force top-k except where the two candidates are within that noise of each other."""
+    res = {}
+    for hop, (qk, Dk, Ik) in enumerate((("q", "D", "I"), ("q2", "D2", "I2")), 1):
+        q = out[qk].float().contiguous()
+        Dm, Im = out[Dk], out[Ik]
+        nq = q.shape[0]
+        q64 = q.double()
+        run_s = torch.full((nq, beam), -float("inf"), device=device)
+        run_i = torch.full((nq, beam), -1, dtype=torch.int64, device=device)
+        exact_err = 0.0
+        c0, c1 = lo // CHUNK_ROWS, (hi - 1) // CHUNK_ROWS
+        for c in range(c0, c1 + 1):
+            base = c * CHUNK_ROWS
+            blk = corpus_chunk(0, c, CHUNK_ROWS, d, device)
+            a, b = max(lo, base) - base, min(hi, base + CHUNK_ROWS) - base
+            sc = q @ blk[a:b].T                                      # [nq, rows] fp32
+            s, i = torch.topk(sc, min(beam, b - a), dim=1)
+            cat_s, cat_i = torch.cat([run_s, s], 1), torch.cat([run_i, i + base + a], 1)
+            run_s, o = torch.topk(cat_s, beam, dim=1)
+            run_i = torch.gather(cat_i, 1, o)
+            # exact fp64 score of the returned rows that live in this chunk
+            gi = Im  # global row ids
+            sel = (gi >= base + a) & (gi < base + b)
+            if bool(sel.any()):
+                qi, kj = sel.nonzero(as_tuple=True)
+                rows = blk[(gi[qi, kj] - base)].double()
+                ex = (rows * q64[qi]).sum(1)
+                exact_err = max(exact_err, float((ex - Dm[qi, kj].double()).abs().max()))
+            del blk, sc
+        kth = Dm[:, beam - 1]
+        beaten = float((run_s[:, beam - 1] - kth).max())          # > 0: brute force found a better k-th row (beyond noise -> wrong)
+        if hi - lo < n_total:  # a shard sees only its own rows: the id comparison needs all of them (done when every rank passes the two bounds)
+            same = near = torch.ones_like(Im, dtype=torch.bool)
+        else:
+            same = (run_i == Im)
+            near = (run_s - Dm).abs() <= 2e-3                      # a different id is acceptable only inside the matmul noise
+        res[f"hop{hop}_returned_score_vs_fp64_maxabs"] = round(exact_err, 6)
+        res[f"hop{hop}_bruteforce_kth_minus_returned_kth_max"] = round(beaten, 6)
+        res[f"hop{hop}_id_agreement_with_bruteforce"] = round(float(same.float().mean()), 6)
+        res[f"hop{hop}_ok"] = bool(exact_err <= 1e-3 and beaten <= 2e-3 and bool((same | near).all()))
+    res["full_size_exact"] = bool(res["hop1_ok"] and res["hop2_ok"])
+    return res
+
+
+def build_pipeline(args, world, rank, device, dist, weak):
+    from multihop_dense_retrieval_amd import index as mdr_index
+    from multihop_dense_retrieval_amd import mhop
+    N, d, B = args.rows, args.dim, args.batch
+    skw = {"storage": "bf16"} if args.storage == "bf16" else {}
+    if world > 1:
+        sidx = mdr_index.ShardedIndexFlatIP(d, N, local_index=mdr_index.IndexFlatIP(d, device=device, **skw))
+        lo, hi = sidx.lo, sidx.hi
+        local = sidx.local
+    else:
+        local = mdr_index.IndexFlatIP(d, device=device, **skw)
+        sidx = local
+        lo, hi = 0, N
+    local.reserve(hi - lo)
+    # planted hop-1 answers make the MIPS-only mode self-checking at full size: question i's best row is p_i
+    GB = B * world if weak else B  # questions per step over all ranks
+    planted = (torch.arange(GB, device=device, dtype=torch.int64) * 48_611 + 17) % N
+    kept = build_shard(local, lo, hi, d, device, keep_rows=planted)
+    rows_sum = torch.zeros((GB, d), device=device)
+    for sel, rows in kept:
+        rows_sum[sel] += rows
+    if world > 1:
+        dist.all_reduce(rows_sum)
+    if weak:  # this rank's own questions
+        rows_sum, planted = rows_sum[rank * B:(rank + 1) * B].contiguous(), planted[rank * B:(rank + 1) * B]
+    return sidx, local, lo, hi, GB, planted, rows_sum
+
+
+def timed_steps(pipe, args, world, device, dist):
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pipe.step()
+    barrier()
+    pipe.reset_kernel_timers()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipe.step()
+    barrier()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return out, elapsed
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,82 +241,63 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    from multihop_dense_retrieval_amd import index as mdr_index
     from multihop_dense_retrieval_amd import mhop
 
     N, d, B = args.rows, args.dim, args.batch
-    skw = {"storage": "bf16"} if args.storage == "bf16" else {}
-    t0 = time.time()
-    if world > 1:
-        sidx = mdr_index.ShardedIndexFlatIP(d, N, local_index=mdr_index.IndexFlatIP(d, device=device, **skw))
-        lo, hi = sidx.lo, sidx.hi
-        local = sidx.local
-    else:
-        local = mdr_index.IndexFlatIP(d, device=device, **skw)
-        sidx = local
-        lo, hi = 0, N
-    local.reserve(hi - lo)
-    # planted hop-1 answers make the run self-checking at full size: question i's best row is p_i
     weak = world > 1 and args.scaling == "weak"
-    GB = B * world if weak else B  # questions per step over all ranks
-    planted = (torch.arange(GB, device=device, dtype=torch.int64) * 48_611 + 17) % N
-    kept = build_shard(local, lo, hi, d, device, keep_rows=planted)
-    rows_sum = torch.zeros((GB, d), device=device)
-    for sel, rows in kept:
-        rows_sum[sel] += rows
-    if world > 1:
-        dist.all_reduce(rows_sum)
-    if weak:  # this rank's own questions
-        rows_sum, planted = rows_sum[rank * B:(rank + 1) * B].contiguous(), planted[rank * B:(rank + 1) * B]
+    t0 = time.time()
+    sidx, local, lo, hi, GB, planted, rows_sum = build_pipeline(args, world, rank, device, dist, weak)
     torch.cuda.synchronize()
     build_s = time.time() - t0
 
     pipe = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device,
                                 max_q_len=args.max_q_len, max_q_sp_len=args.max_q_sp_len,
                                 use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank, world=world, weak=weak)
+    out, elapsed = timed_steps(pipe, args, world, device, dist)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        pipe.step()
-    barrier()
-    pipe.reset_kernel_timers()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        out = pipe.step()
-    barrier()
-    elapsed = time.perf_counter() - t1
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # self-check at full size: MIPS-only mode plants the hop-1 answers
+    # self-checks, outside the timed region: structural properties + exactness against a brute-force pass over ALL rows
     ok = pipe.self_check(out, planted)
+    if not args.no_verify:
+        ok.update(verify_full_size(out, lo, hi, N, d, device, args.beam))
+        if world > 1:  # a shard only sees its own rows: the claim holds when it holds on every rank
+            flag = torch.tensor([1.0 if ok["full_size_exact"] else 0.0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok["full_size_exact"] = bool(flag.item() > 0.5)
 
     ms_per_step = elapsed / args.steps * 1e3
     qps = GB * args.steps / elapsed
-    search_ms = pipe.search_kernel_ms()  # HIP-event average over every timed search call (rank-local)
-    stream_bytes = local.stream_bytes()
-    # one search call streams the shard once per group of <= 128 queries (the kernel's design point: 8 waves x 16 queries);
-    # under weak scaling a rank searches all 100 N queries in its shard, i.e. ceil(100 N / 128) passes per call
-    passes = max(1, -(-GB // 128))
-    stream_bytes *= passes
-    achieved = stream_bytes / (search_ms * 1e-3) / 1e9 if search_ms > 0 else 0.0
-    traffic, traffic_src = args.pmc_traffic, "--pmc-traffic"
-    if traffic is None:
-        for name, (ratio, src) in PMC_TRAFFIC_RATIO.items():
-            if name in local.last_kernel() and d == 768 and args.storage != "bf16":
-                traffic, traffic_src = float(round(stream_bytes * ratio)), f"{src} (measured ratio {ratio} x algorithmic bytes)"
-    roofline = {"bound": "hbm", "kernel": local.last_kernel(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
-                "algorithmic_bytes_per_launch": stream_bytes,
-                "designed_hbm_bytes_per_launch": stream_bytes // 2 if ("screen" in local.last_kernel() and args.storage != "bf16") else stream_bytes, "avg_launch_ms": round(search_ms, 4),
-                "launches_timed": pipe.search_calls_timed(), "corpus_passes_per_launch": passes}
 
+    # ---- roofline of the dominant MIPS kernel: PHYSICAL HBM bytes / HIP-event time of each search call ----------------
+    calls = pipe.search_calls()  # [(ms, nq)] of every timed local search (rank-local)
+    shard_bytes = local.stream_bytes()  # N_pad * d * 4 (fp32 index) or * 2 (bf16): the corpus read once
+    qpp = local.queries_per_pass(args.beam)
+    passes = [max(1, -(-nq // qpp)) for _, nq in calls]
+    tot_ms = sum(ms for ms, _ in calls)
+    alg_bytes = float(sum(shard_bytes * p for p in passes))
+    kname = local.last_kernel()
+    ratio, src = (1.0, "designed (no counter profile for this kernel / shape)")
+    if args.pmc_traffic is None:
+        for name, (r_, src_) in PMC_TRAFFIC_RATIO.items():
+            if name in kname and d == 768 and args.storage != "bf16":
+                ratio, src = r_, f"{src_} (measured FETCH_SIZE x 2 / algorithmic bytes = {r_})"
+        hbm_bytes = alg_bytes * ratio
+    else:
+        hbm_bytes, src = float(args.pmc_traffic) * len(calls), "--pmc-traffic"
+    n_calls = max(1, len(calls))
+    achieved = hbm_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+    alg_rate = alg_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": round(hbm_bytes / n_calls), "traffic_source": src,
+                "algorithmic_bytes_per_launch": round(alg_bytes / n_calls),
+                "algorithmic_GBps": round(alg_rate, 1),
+                "algorithmic_over_physical": round(alg_bytes / hbm_bytes, 3) if hbm_bytes > 0 else None,
+                "avg_launch_ms": round(tot_ms / n_calls, 4), "launches_timed": len(calls),
+                "corpus_passes_per_launch": round(float(np.mean(passes)), 3) if passes else 0, "queries_per_pass": qpp,
+                "note": "achieved/frac = physical HBM bytes (rocprofv3 FETCH_SIZE, gfx950-corrected) / HIP-event time of the whole search call; "
+                        "the screen kernels stream only the fp16 hi plane, so the fp32-equivalent (algorithmic) rate is reported separately"}
+
+    stage = pipe.stage_ms()
     result = {
         "metric": "queries/sec (2-hop, beam-size x topk) over 5Mx768 index",
         "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -204,8 +312,40 @@ def main():
                    "encoder": pipe.encoder_desc(), "index_build_s": round(build_s, 2)},
         "roofline": roofline,
         "self_check": ok,
-        "stage_ms": pipe.stage_ms(),
+        "stage_ms": stage,
     }
+    if pipe.use_encoder:
+        # ---- second roofline entry: the encoder (MFMA-bound), the larger share of the step --------------------------------
+        q_lens = pipe.q_len.cpu().numpy()
+        sp_lens = out["mask2"].sum(1).cpu().numpy()
+        e1, p1 = encoder_flops(q_lens, args.max_q_len)
+        e2, p2 = encoder_flops(sp_lens, args.max_q_sp_len)
+        enc_ms = stage["hop1_encode"] + stage["hop2_encode"]
+        if world > 1 and not weak:  # strong scaling: each rank encodes 1/world of the rows, the rest of the stage is the all-gather
+            e1, p1, e2, p2 = e1 / world, p1 / world, e2 / world, p2 / world
+        ach = (e1 + e2) / (enc_ms * 1e-3) / 1e12
+        result["roofline_encoder"] = {
+            "bound": "mfma", "kernel": "mdr_encoder_forward (gemm_big / attention_stream / layernorm kernels, hipGraph replay)",
+            "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+            "executed_flop_per_step": round(e1 + e2), "padded_equivalent_flop_per_step": round(p1 + p2),
+            "padded_equivalent_TFLOPs": round((p1 + p2) / (enc_ms * 1e-3) / 1e12, 1),
+            "hop1": {"ms": stage["hop1_encode"], "tokens": int(q_lens.sum()), "TFLOPs": round(e1 / (stage["hop1_encode"] * 1e-3) / 1e12, 1)},
+            "hop2": {"ms": stage["hop2_encode"], "tokens": int(sp_lens.sum()), "TFLOPs": round(e2 / (stage["hop2_encode"] * 1e-3) / 1e12, 1)},
+            "share_of_step": round(enc_ms / ms_per_step, 3),
+            "note": "executed FLOPs (masked tokens dropped, last layer CLS-only) / HIP-event stage time on the launch stream; peak = dense fp16 MFMA"}
+    result["stage_share"] = {"encoder": round((stage.get("hop1_encode", 0) + stage.get("hop2_encode", 0)) / ms_per_step, 3),
+                             "mips": round((stage.get("hop1_search", 0) + stage.get("hop2_search", 0)) / ms_per_step, 3)}
+
+    if world > 1 and weak and not args.no_strong:
+        # The same job with ONE 100-question batch shared by all ranks (the reference's fixed --batch-size): a sub-result of
+        # the same JSON line, so a scaling run carries the strong-scaling number next to the weak one.
+        del pipe, out
+        pipe_s = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
+                                      max_q_sp_len=args.max_q_sp_len, use_encoder=not args.no_encoder,
+                                      planted_rows=torch.zeros((B, d), device=device), rank=rank, world=world, weak=False)
+        _, el_s = timed_steps(pipe_s, args, world, device, dist)
+        result["strong_scaling"] = {"value": round(B * args.steps / el_s, 2), "unit": "queries/s", "ms_per_step": round(el_s / args.steps * 1e3, 4),
+                                    "global_batch": B, "note": "one batch of --batch questions for all ranks: encoder slices split over ranks + all-gather"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, device)

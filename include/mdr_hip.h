@@ -12,8 +12,11 @@
  *     error on the calling thread is mdr_last_error(). Nothing throws, nothing calls exit().
  *   - pointers named *_dev are DEVICE pointers on the handle's device; *_host are host pointers.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). All work is enqueued
- *     asynchronously on it; no entry point synchronises the device except mdr_index_add with a host
- *     source (which must finish reading the host buffer before it returns).
+ *     asynchronously on it; no entry point synchronises the device except mdr_index_add /
+ *     mdr_index_reserve (index construction, not the search loop): add() waits on `stream` for host AND
+ *     device sources, because it validates the rows (range / non-finite) before it makes them visible
+ *     (ntotal) and must have consumed a host buffer before it returns. It must therefore not be called
+ *     while `stream` is being captured into a hipGraph; search / merge / encoder / assemble may be.
  *   - the caller owns every buffer it passes (queries, results, workspace); a handle owns only its
  *     own storage (corpus shard, encoder weight copies).
  *   - one handle per (process, device); calls on one handle are not re-entrant.
@@ -73,6 +76,10 @@ int64_t mdr_index_ntotal(const mdr_index* h);
 int mdr_index_dim(const mdr_index* h);
 /* bytes of HBM one search call streams for the corpus (= ntotal_padded * d * bytes/elem) */
 int64_t mdr_index_stream_bytes(const mdr_index* h);
+
+/* Queries one corpus pass of mdr_index_search serves for this k (a call with nq queries streams the shard
+ * ceil(nq / this) times): the accounting bench.py's roofline uses. */
+int mdr_index_queries_per_pass(const mdr_index* h, int k);
 
 /* Workspace one search call needs (device memory, 256-byte aligned, contents don't persist). */
 size_t mdr_index_search_workspace_bytes(const mdr_index* h, int nq, int k);

@@ -7,7 +7,8 @@ import torch  # noqa: F401  -- must be imported first: its bundled libamdhip64.s
 #                              both torch and libmdrhip.so must share (same SONAME -> one runtime).
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdrhip.so")
+# MDR_LIB_PATH: measurement only -- A/B a variant build of the SAME sources (build.py --out=...); never a different backend
+LIB_PATH = os.environ.get("MDR_LIB_PATH") or os.path.join(_HERE, "libmdrhip.so")
 
 MDR_DT_F32, MDR_DT_BF16, MDR_DT_F16 = 0, 1, 2
 MDR_STORE_F32X2H, MDR_STORE_BF16 = 0, 1
@@ -41,6 +42,7 @@ _SIGNATURES = {
     "mdr_index_ntotal": (_c.c_int64, [_c.c_void_p]),
     "mdr_index_dim": (_c.c_int, [_c.c_void_p]),
     "mdr_index_stream_bytes": (_c.c_int64, [_c.c_void_p]),
+    "mdr_index_queries_per_pass": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "mdr_index_search_workspace_bytes": (_c.c_size_t, [_c.c_void_p, _c.c_int, _c.c_int]),
     "mdr_index_search": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                     _c.c_void_p, _c.c_size_t, _c.c_void_p]),

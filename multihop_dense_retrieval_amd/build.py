@@ -28,18 +28,23 @@ def _stale():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build_lib(force=False, verbose=True):
-    if not force and not _stale():
+def build_lib(force=False, verbose=True, defines=(), out=None):
+    """defines / out: build a measurement VARIANT of the library next to the product one (e.g. defines=["MDR_MIPS_DMA_AUX=2"],
+    out="libmdrhip_nt.so"); a process selects it with MDR_LIB_PATH (scripts/gpu_ab.sh). The product build takes neither."""
+    target = LIB if out is None else os.path.join(HERE, out)
+    if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-Wno-unused-variable", "-I", INCLUDE] + sources() + ["-o", LIB + ".tmp"]
+           "-Wno-unused-variable", "-I", INCLUDE] + ["-D" + d for d in defines] + sources() + ["-o", target + ".tmp"]
     if verbose:
         print("[mdr build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(target + ".tmp", target)
+    return target
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a[6:] for a in sys.argv[1:] if a.startswith("--out=")]
+    print(build_lib(force="--force" in sys.argv, defines=defs, out=outs[0] if outs else None))

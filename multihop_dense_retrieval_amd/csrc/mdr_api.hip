@@ -1,6 +1,9 @@
 // csrc/mdr_api.hip -- error state and version of libmdrhip.so (include/mdr_hip.h).
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
+#include <set>
+#include <utility>
 
 #include "mdr_common.h"
 
@@ -19,9 +22,21 @@ int set_error(int code, const char* fmt, ...) {
     return code;
 }
 
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    MDR_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return MDR_OK;
+    MDR_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({kernel, dev});
+    return MDR_OK;
+}
+
 }  // namespace mdr
 
 extern "C" {
 const char* mdr_last_error(void) { return mdr::last_error_buf(); }
-const char* mdr_version(void) { return "mdr-hip 0.1 (gfx950)"; }
+const char* mdr_version(void) { return "mdr-hip 0.2 (gfx950)"; }
 }

@@ -29,6 +29,10 @@ int set_error(int code, const char* fmt, ...);
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: remember which (kernel, current device) pairs have
+// been opted in, so a second device in one process (mdr_index_create(device) allows it) is opted in as well.
+int ensure_dynamic_lds(const void* kernel, int bytes);
+
 // RAII device switch: every entry point runs on its handle's device and restores the caller's.
 struct DeviceGuard {
     int prev = -1;

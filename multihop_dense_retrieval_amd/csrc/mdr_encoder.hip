@@ -1220,11 +1220,7 @@ Workspace carve(const mdr_encoder_config& c, int B, int L, char* base) {
 template <int EPI, typename C>
 int launch_gemm_cfg(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
                     const _Float16* res, int ldr, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_f16_kernel<EPI, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        attr = true;
-    }
+    { int rc_ = ensure_dynamic_lds((const void*)gemm_f16_kernel<EPI, C>, C::LDS_BYTES); if (rc_) return rc_; }
     const int blocks = (N / C::BN) * ((M_cap + C::BM - 1) / C::BM);
     hipLaunchKernelGGL((gemm_f16_kernel<EPI, C>), dim3(blocks), dim3(C::THREADS), C::LDS_BYTES, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr);
     MDR_HIP_TRY(hipGetLastError());
@@ -1242,11 +1238,7 @@ template <int EPI, typename C>
 int launch_gemm_persist(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
                         int M_est, int num_cus, hipStream_t st) {
     constexpr int lds = C::LDS_BYTES + kPersistBiasMax * 4;
-    static bool attr = false;
-    if (!attr) {
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI, C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    { int rc_ = ensure_dynamic_lds((const void*)gemm_persist_kernel<EPI, C>, lds); if (rc_) return rc_; }
     const int grid = num_cus / 8 * 8;
     const char* em = getenv("MDR_GEMM_EPI");  // measurement knob: 0 stores after the tile, 1 deferred, 2 deferred + two stores may stay in flight
     hipLaunchKernelGGL((gemm_persist_kernel<EPI, C>), dim3(grid), dim3(C::THREADS), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo,
@@ -1259,11 +1251,7 @@ template <int EPI>
 int launch_gemm_big(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
                     int M_est, int num_cus, hipStream_t st) {
     constexpr int lds = GemmB2::LDS_BYTES + kPersistBiasMax * 4 + 8 * 2048;  // slots + bias + per-wave epilogue scratch
-    static bool attr = false;
-    if (!attr) {
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)gemm_big_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    { int rc_ = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI>, lds); if (rc_) return rc_; }
     const int grid = num_cus / 8 * 8;
     hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(grid), dim3(512), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo);
     MDR_HIP_TRY(hipGetLastError());
@@ -1317,12 +1305,8 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
 
 template <int NT>
 int launch_attention(const _Float16* qkv, const int* cu, int B, int L, int H, int heads, _Float16* ctx, hipStream_t st) {
-    static bool attr = false;
     constexpr int lds = attention_lds_bytes<NT>();
-    if (!attr) {
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)attention_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    { int rc_ = ensure_dynamic_lds((const void*)attention_kernel<NT>, lds); if (rc_) return rc_; }
     dim3 grid(heads, B);
     hipLaunchKernelGGL((attention_kernel<NT>), grid, dim3(512), lds, st, qkv, cu, H, ctx);
     MDR_HIP_TRY(hipGetLastError());
@@ -1331,12 +1315,8 @@ int launch_attention(const _Float16* qkv, const int* cu, int B, int L, int H, in
 
 template <int NTC>
 int launch_attention_stream(const _Float16* qkv, const int* cu, int B, int L, int H, int heads, _Float16* ctx, hipStream_t st) {
-    static bool attr = false;
     constexpr int lds = NTC * 16 * 128 * 2;
-    if (!attr) {
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)attention_stream_kernel<NTC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    { int rc_ = ensure_dynamic_lds((const void*)attention_stream_kernel<NTC>, lds); if (rc_) return rc_; }
     dim3 grid(heads, B, (L + 127) / 128);
     hipLaunchKernelGGL((attention_stream_kernel<NTC>), grid, dim3(512), lds, st, qkv, cu, H, ctx);
     MDR_HIP_TRY(hipGetLastError());

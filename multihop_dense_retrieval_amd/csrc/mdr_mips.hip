@@ -254,6 +254,12 @@ __device__ __forceinline__ void consider(float s, unsigned row, bool valid, floa
 // ---- the stream kernel -------------------------------------------------------------------------------
 #define MDR_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define MDR_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+// cache policy of the corpus stream (aux bits of global_load_lds: 0 = default, 2 = nt). The corpus is read once per
+// search and is 30x the Infinity Cache, so the stream is non-temporal: measured 1.698 vs 1.733 ms per 5M-row search
+// (interleaved A/B of two builds of these sources, gpurun_out r02a; scripts/gpu_ab.sh rebuilds the comparison).
+#ifndef MDR_MIPS_DMA_AUX
+#define MDR_MIPS_DMA_AUX 2
+#endif
 
 // DMA one row-block (hi plane then lo plane, NKB KiB each) into an LDS slot: 2*NKB pieces over 8 waves
 template <int NKB>
@@ -265,7 +271,7 @@ __device__ __forceinline__ void issue_row_block(const char* __restrict__ Xhi, co
         const char* plane = piece < NKB ? Xhi : Xlo;
         const int kb = piece < NKB ? piece : piece - NKB;
         const char* g = plane + ((size_t)rb * NKB + kb) * kFragBytes + lane * 16;
-        __builtin_amdgcn_global_load_lds(MDR_GPTR(g), MDR_LPTR(slot + piece * kFragBytes), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(MDR_GPTR(g), MDR_LPTR(slot + piece * kFragBytes), 16, 0, MDR_MIPS_DMA_AUX);
     }
 }
 
@@ -410,7 +416,7 @@ __device__ __forceinline__ void issue_super_block(const char* __restrict__ Xhi, 
     const char* g = Xhi + ((size_t)sb * 2 * NKB + (size_t)wave * CPW) * kFragBytes + lane * 16;
     char* l = slot + wave * CPW * kFragBytes;
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) __builtin_amdgcn_global_load_lds(MDR_GPTR(g + c * kFragBytes), MDR_LPTR(l + c * kFragBytes), 16, 0, 0);
+    for (int c = 0; c < CPW; ++c) __builtin_amdgcn_global_load_lds(MDR_GPTR(g + c * kFragBytes), MDR_LPTR(l + c * kFragBytes), 16, 0, MDR_MIPS_DMA_AUX);
 }
 
 __device__ __forceinline__ unsigned load_u32_l2(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1283,12 +1289,9 @@ template <bool BF>
 int run_screen(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, const char* qhi, u64* best, hipStream_t st) {
     constexpr int NKB = 24;
     const size_t lds_bytes = 3 * (size_t)NKB * 2 * kFragBytes;
-    static bool attr = false;
-    if (!attr) {
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screen_kernel<NKB, 0, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screen_kernel<NKB, 1, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr = true;
-    }
+    int rc_ = ensure_dynamic_lds((const void*)mips_screen_kernel<NKB, 0, BF>, (int)lds_bytes);
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen_kernel<NKB, 1, BF>, (int)lds_bytes);
+    if (rc_) return rc_;
     float* bound = (float*)(ws + p.off_bound);
     unsigned* gmax = (unsigned*)(ws + p.off_gmax);
     u64* scand = (u64*)(ws + p.off_scand);
@@ -1326,13 +1329,10 @@ int run_screenk(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
     constexpr int NKB = 24;
     const size_t lds_bytes = 3 * (size_t)NKB * 2 * kFragBytes;
     const size_t merge_lds = (size_t)kMergeKLds * 8;
-    static bool attr = false;
-    if (!attr) {
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screen_kernel<NKB, 2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_screenk_kernel<NKB, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)merge_screenk_kernel<BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_lds));
-        attr = true;
-    }
+    int rc_ = ensure_dynamic_lds((const void*)mips_screen_kernel<NKB, 2, BF>, (int)lds_bytes);
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screenk_kernel<NKB, BF>, (int)lds_bytes);
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)merge_screenk_kernel<BF>, (int)merge_lds);
+    if (rc_) return rc_;
     float* bound = (float*)(ws + p.off_bound);
     float* tau0 = (float*)(ws + p.off_gmax);
     unsigned* wgmax = (unsigned*)(ws + p.off_scand);
@@ -1476,6 +1476,11 @@ int mdr_index_set_variant(mdr_index* h, int variant) {
 
 const char* mdr_index_last_kernel(const mdr_index* h) { return h ? h->last_kernel : "none"; }
 
+int mdr_index_queries_per_pass(const mdr_index* h, int k) {
+    if (!h || k < 1 || k > kKMax) return 0;
+    return make_plan(h, 1, k).path == PATH_GENERIC ? kGenericQ : kStreamQ;
+}
+
 size_t mdr_index_search_workspace_bytes(const mdr_index* h, int nq, int k) {
     if (!h || nq < 0 || k < 1 || k > kKMax) return 0;
     return make_plan(h, nq, k).total;
@@ -1523,7 +1528,6 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
     u64* best = (u64*)(ws + p.off_best);
     char* qhi = ws + p.off_qhi;
     char* qlo = ws + p.off_qlo;
-    static bool attr_done[2] = {false, false};
     rc = launch_convert(bf, q_dev, (long long)nq, (long long)ngroups * kStreamQ, h->d, 0, qhi, qlo, h->flags + 1, st);
     if (rc) return rc;
 
@@ -1539,10 +1543,8 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
             h->last_kernel = "mips_stream_kernel<24,0>";
         }
         if (!bf) {
-            if (!attr_done[0]) {
-                MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_stream_kernel<NKB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * rb_bytes)));
-                attr_done[0] = true;
-            }
+            rc = ensure_dynamic_lds((const void*)mips_stream_kernel<NKB, 0>, (int)(3 * rb_bytes));
+            if (rc) return rc;
             const int Gx = (int)(n_rb < h->num_cus ? n_rb : h->num_cus);
             for (int gi = 0; gi < ngroups; ++gi) {
                 const int nqg = nq - gi * kStreamQ < kStreamQ ? nq - gi * kStreamQ : kStreamQ;
@@ -1576,10 +1578,8 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
     int* cnt = (int*)(ws + p.off_cnt);
     u64* kth = (u64*)(ws + p.off_kth);
     const size_t lds_bytes = 3 * rb_bytes + kStreamQ * sizeof(int);
-    if (!attr_done[1]) {
-        MDR_HIP_TRY(hipFuncSetAttribute((const void*)mips_stream_kernel<NKB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_done[1] = true;
-    }
+    rc = ensure_dynamic_lds((const void*)mips_stream_kernel<NKB, 1>, (int)lds_bytes);
+    if (rc) return rc;
     for (int gi = 0; gi < ngroups; ++gi) {
         const int nqg = nq - gi * kStreamQ < kStreamQ ? nq - gi * kStreamQ : kStreamQ;
         MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.Gx * kStreamQ * 4, st));

@@ -108,6 +108,10 @@ class IndexFlatIP:
         """HBM bytes one search call reads for the corpus (algorithmic bytes of the roofline)."""
         return int(_lib.lib().mdr_index_stream_bytes(self._h))
 
+    def queries_per_pass(self, k=1):
+        """Queries one pass over the shard serves (a search with nq queries reads the corpus ceil(nq / this) times)."""
+        return int(_lib.lib().mdr_index_queries_per_pass(self._h, int(k)))
+
     def set_variant(self, v):
         """Test hook: 0 auto, 1 generic fp32 kernel, 2 exact 3-MFMA stream kernel, 3 screen + refine (k == 1)."""
         _lib.check(_lib.lib().mdr_index_set_variant(self._h, int(v)))
@@ -200,9 +204,18 @@ class ShardedIndexFlatIP:
         """Convenience: slice this rank's rows out of a full (e.g. mmap'ed) matrix."""
         self.local.add(xb[self.lo:self.hi])
 
-    def search(self, q, k):
+    def search(self, q, k, force=False):
+        """faiss-style surface over the shards: numpy in -> numpy out, cuda tensor in -> cuda tensors out. With the real
+        local index the exchange and the merge always run on DEVICE tensors (RCCL takes device buffers and mdr_topk_merge
+        is a HIP kernel): numpy queries are uploaded once and only the merged result comes back to the host."""
+        as_numpy = isinstance(q, np.ndarray)
+        if as_numpy and isinstance(self.local, IndexFlatIP):
+            qd = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(self.local.device)
+            D, I = self.local.search_device(qd, k)
+            Dm, Im = self.search_gathered(D, I, force=force)
+            return Dm.cpu().numpy(), Im.cpu().numpy()
         D, I = self.local.search(q, k)
-        return self.search_gathered(D, I)
+        return self.search_gathered(D, I, force=force)
 
     def search_gathered(self, D, I, force=False):
         """Exchange this rank's (D, I) [nq, k] with every other rank and merge; identical on all ranks.

@@ -80,7 +80,11 @@ class _HipRobertaEncoder:
         self._shapes = expected_state_dict_shapes(config)
         self._h = ctypes.c_void_p()
         self._ws = None
-        self._graphs = {}
+        self._graphs = OrderedDict()  # (B, L bucket) -> capture, LRU order
+        self._seen = {}
+        self.capture_on_first_use = False
+        self.graph_captures = 0
+        self.graph_replays = 0
         self.use_graphs = True
         self.device = None
         self.training = False
@@ -123,6 +127,9 @@ class _HipRobertaEncoder:
         return self
 
     # -- the forward ----------------------------------------------------------------------------------------
+    GRAPH_L_BUCKET = 32       # graph keys use seq_len rounded up to this (padding columns are free: execution is un-padded)
+    GRAPH_CACHE_ENTRIES = 24  # LRU bound on captured shapes
+
     def encode_seq(self, input_ids, mask):
         if not self._h.value:
             raise RuntimeError("encoder has no weights on a device: call load_saved(...)/load_state_dict(...) and .to('cuda') first")
@@ -155,12 +162,32 @@ class _HipRobertaEncoder:
     def _encode_graphed(self, ids, msk):
         """One forward is ~140 short kernel launches; for the small batches of the retrieval loop (and for each
         rank's slice under multi-GPU data parallelism) the launch gaps dominate. The launch sequence depends only
-        on (B, L), so it is captured once per shape into a hipGraph and replayed (static input/output buffers)."""
-        key = tuple(ids.shape)
+        on (B, L), so it is captured into a hipGraph and replayed (static input/output buffers).
+
+        Shapes are keyed by (B, L rounded up to GRAPH_L_BUCKET): corpus encoding pads every batch to its own longest
+        passage (em_collate), which would otherwise make nearly every batch a new shape. The extra columns are pad/mask-0
+        and cost nothing (masked tokens are dropped on the device before any arithmetic). A shape is captured the SECOND
+        time it is seen (a one-off shape runs eagerly, without the warm-up + capture cost); the cache is LRU-bounded and
+        is dropped as a whole when the workspace is re-allocated (captures hold raw pointers into it)."""
+        B, L = ids.shape
+        Lb = min(512, -(-L // self.GRAPH_L_BUCKET) * self.GRAPH_L_BUCKET)
+        key = (B, Lb)
         ent = self._graphs.get(key)
+        if ent is not None and ent[4] is not self._ws:  # stale: the workspace moved since the capture
+            self._graphs.clear()
+            ent = None
         if ent is None:
-            sid, smk = ids.clone(), msk.clone()
-            sout = torch.empty((key[0], self.config.hidden_size), dtype=torch.float32, device=self.device)
+            seen = self._seen.get(key, 0) + 1
+            self._seen[key] = seen
+            if seen < 2 and not self.capture_on_first_use:
+                out = torch.empty((B, self.config.hidden_size), dtype=torch.float32, device=self.device)
+                self._forward_into(ids, msk, out)
+                return out
+            sid = torch.full((B, Lb), int(self.config.pad_token_id), dtype=torch.int64, device=self.device)
+            smk = torch.zeros((B, Lb), dtype=torch.int64, device=self.device)
+            sid[:, :L].copy_(ids)
+            smk[:, :L].copy_(msk)
+            sout = torch.empty((B, self.config.hidden_size), dtype=torch.float32, device=self.device)
             # the capture freezes the tile-shape choices: tell the library how full this shape's batches are (the first
             # batch stands for the later ones of the same shape; only speed depends on it). One sync, at capture time only.
             fill = float(smk.sum().item()) / float(smk.numel()) if os.environ.get("MDR_FILL_HINT", "1") != "0" else 0.0
@@ -174,16 +201,19 @@ class _HipRobertaEncoder:
             finally:
                 _lib.check(_lib.lib().mdr_encoder_set_fill_hint(self._h, 0.0))
             ent = (graph, sid, smk, sout, self._ws)
-            if len(self._graphs) >= 16:  # bounded cache (ragged last batches, corpus encoding with many widths)
-                self._graphs.pop(next(iter(self._graphs)))
+            while len(self._graphs) >= self.GRAPH_CACHE_ENTRIES:
+                self._graphs.popitem(last=False)  # least recently used
             self._graphs[key] = ent
-        graph, sid, smk, sout, ws = ent
-        if ws is not self._ws:  # the workspace was re-allocated (a larger shape came by): the capture is stale
-            del self._graphs[key]
-            return self._encode_graphed(ids, msk)
-        sid.copy_(ids)
-        smk.copy_(msk)
+            self.graph_captures += 1
+            return sout.clone()  # the warm-up / capture pair already produced this batch's result
+        self._graphs.move_to_end(key)
+        graph, sid, smk, sout, _ = ent
+        sid[:, :L].copy_(ids)
+        smk[:, :L].copy_(msk)
+        if L < Lb:
+            smk[:, L:].zero_()
         graph.replay()
+        self.graph_replays += 1
         return sout.clone()
 
     # -- internals ----------------------------------------------------------------------------------------------
@@ -292,21 +322,3 @@ def move_to_cuda(sample):
 
     return mv(sample)
 
-
-def smoke_check():
-    """Tiny-geometry encoder forward on cuda:0 against the numpy restatement (used by __graft_entry__.smoke)."""
-    import numpy as np
-    from oracle import roberta_oracle, seeded
-    geom = seeded.TINY
-    sd = seeded.make_state_dict(5, geom)
-    cfg = RobertaConfig(vocab_size=geom["vocab"], hidden_size=geom["hidden"], num_hidden_layers=geom["layers"],
-                        num_attention_heads=geom["heads"], intermediate_size=geom["ffn"])
-    m = RobertaRetriever(cfg, None)
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    m.to("cuda:0")
-    ids, mask = seeded.make_token_batch(5, "smoke", 6, 40, geom["vocab"])
-    out = m.encode_q(torch.from_numpy(ids), torch.from_numpy(mask), None).cpu().numpy()
-    ref = roberta_oracle.encode(sd, geom, ids, mask, np.float64)
-    err = np.abs(out - ref).max()
-    assert err < 3e-2, f"encoder smoke mismatch: max abs err {err}"
-    return err

@@ -7,6 +7,7 @@ up without a multi-GPU node. Launch: python -m torch.distributed.run --nproc-per
 import os
 import sys
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -30,6 +31,10 @@ for k in (1, 8):
     D, I = sidx.local.search_device(q, k)
     Dm, Im = sidx.search_gathered(D, I, force=True)  # all_gather of the packed int64 buffer + mdr_topk_merge
     assert torch.equal(Dm, D) and torch.equal(Im, I), k
+    # the faiss-style numpy surface over the same collective: host queries in, host results out (this used to hand
+    # CPU tensors to the nccl group and to the HIP merge kernel)
+    Dn, In = sidx.search(q.cpu().numpy(), k, force=True)
+    assert isinstance(Dn, np.ndarray) and np.array_equal(Dn, D.cpu().numpy()) and np.array_equal(In, I.cpu().numpy()), k
 # an encoder graph replay between collectives (the bench's weak-scaling step does exactly this)
 enc = RobertaRetriever.random_init(device=dev, seed=3)
 ids = torch.randint(3, 50265, (16, 40), generator=g, device=dev)

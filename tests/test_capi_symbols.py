@@ -39,3 +39,32 @@ def test_product_path_fails_loudly_without_a_device():
         index.IndexFlatIP(768)
     with pytest.raises(RuntimeError):
         retriever.RobertaRetriever(retriever.RobertaConfig(), None).to("cpu")
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch it.
+    Walk every module of the package (and the drop-in entry points under scripts/) and fail on any import of it, static or
+    dynamic (importlib / __import__ with the literal name), or any dlopen of oracle/liboracle.so."""
+    import ast
+    import glob
+    pkg = os.path.join(ROOT, "multihop_dense_retrieval_amd")
+    files = sorted(glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True)) + [
+        os.path.join(ROOT, "scripts", "encode_corpus.py")] + sorted(glob.glob(os.path.join(ROOT, "scripts", "eval", "*.py")))
+    assert len(files) > 10
+    for path in files:
+        tree = ast.parse(open(path).read(), path)
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            elif isinstance(node, ast.Constant) and isinstance(node.value, str) and node is not ast.get_docstring:
+                # string constants that would name the checker in a dynamic import / dlopen
+                names = [node.value] if re.fullmatch(r"oracle(\.\w+)*|.*liboracle\.so", node.value) else []
+            else:
+                continue
+            for n in names:
+                assert not (n == "oracle" or n.startswith("oracle.") or n.endswith("liboracle.so")), f"{path} reaches into oracle/: {n}"
+    # the native sources must not link or include it either
+    for path in glob.glob(os.path.join(pkg, "csrc", "*")):
+        assert "oracle" not in open(path).read(), path
