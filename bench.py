@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true", help="debug: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--pmc-traffic", type=float, default=None, help="HBM bytes per launch from a rocprofv3 --pmc pass")
     ap.add_argument("--no-verify", action="store_true", help="skip the full-size brute-force exactness check after the timed region")
+    ap.add_argument("--dump-ids", default=None, help="rank 0 writes the last step's hop-1 / hop-2 ids and scores to this .npz (tests)")
     ap.add_argument("--no-strong", action="store_true", help="N>1, weak scaling: do not append the strong-scaling sub-result")
     return ap.parse_args()
 
@@ -263,6 +264,9 @@ def main():
             flag = torch.tensor([1.0 if ok["full_size_exact"] else 0.0], device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok["full_size_exact"] = bool(flag.item() > 0.5)
+
+    if args.dump_ids and rank == 0:
+        np.savez(args.dump_ids, I=out["I"].cpu().numpy(), I2=out["I2"].cpu().numpy(), D=out["D"].cpu().numpy(), D2=out["D2"].cpu().numpy())
 
     ms_per_step = elapsed / args.steps * 1e3
     qps = GB * args.steps / elapsed

@@ -43,4 +43,8 @@ def encode_args(argv=None):
     p.add_argument("--is_query_embed", action="store_true")
     # addition of this build (off by default): also write <embed_save_path>.bf16.npy, the matrix as bf16 bit patterns
     p.add_argument("--save_bf16", action="store_true")
+    # addition (default behaviour is result-identical to the reference): passages are tokenised in windows of
+    # predict_batch_size x this many items, sorted by token count inside a window and batched by length; every embedding
+    # still lands in its own row. 1 = the reference's order-of-appearance batches.
+    p.add_argument("--length_bucket_window", type=int, default=16)
     return p.parse_args(argv)

@@ -2,15 +2,55 @@
     collate_tokens   /root/reference/mdr/retrieval/data/data_utils.py:11-29
     EmDataset        /root/reference/mdr/retrieval/data/encode_datasets.py:32-100
     em_collate       /root/reference/mdr/retrieval/data/encode_datasets.py:102-114
-Same names and behaviour; tokenizer calls use the transformers>=4 spelling of the 2.11 API the
-reference was written against (`encode_plus(a, text_pair=b, max_length=n)` == `tok(a, b,
-truncation=True, max_length=n)`: longest-first truncation, special tokens added, no padding)."""
+Same names and behaviour. The reference was written against transformers 2.11 (`encode_plus(a, text_pair=b,
+max_length=n)`: special tokens added, longest-first truncation by the slow tokenizer's pop loop, no padding); the pair
+template and that truncation rule are restated here (encode_pairs_2_11) so the result does not depend on the installed
+HF version, whose fast tokenizers split an odd token budget differently."""
 import csv
 import json
 import os
 import unicodedata
 
 import torch
+
+
+def truncate_longest_first_2_11(la, lb, budget):
+    """Lengths left by transformers 2.11 `truncate_sequences(..., 'longest_first')` (the slow-tokenizer loop the reference
+    runs, requirements.txt:1): tokens are popped one at a time from the LONGER sequence, from the SECOND on a tie, until the
+    pair fits `budget` = max_length - 4 special tokens. Closed form of that loop. (The Rust fast tokenizers split an odd
+    budget the other way round -- floor to the shorter/first, ceil to the longer/second -- so for odd budgets their pair
+    encoding differs from the reference's by the boundary token; tests/test_tokenizer_fidelity.py pins both facts.)"""
+    over = la + lb - budget
+    if over <= 0:
+        return la, lb
+    d = abs(la - lb)
+    if over <= d:  # only the longer sequence is cut
+        return (la - over, lb) if la > lb else (la, lb - over)
+    s, r = min(la, lb), over - d  # both at length s; the remaining r pops alternate, second sequence first
+    return s - r // 2, s - (r + 1) // 2
+
+
+def encode_pairs_2_11(tokenizer, firsts, seconds, max_length, pad_to_max_length):
+    """`encode_plus(a, text_pair=b, max_length=n[, pad_to_max_length=True])` of transformers 2.11 for RoBERTa-family
+    tokenizers on top of ANY HF tokenizer version: the tokenizer only supplies the BPE (each text tokenised on its own, no
+    special tokens, no truncation); the pair template `<s> A </s></s> B </s>`, the reference's truncation rule and the
+    right-padding are applied here. Returns (list of id lists, list of mask lists)."""
+    ta = tokenizer(list(firsts), add_special_tokens=False, truncation=False)["input_ids"]
+    tb = tokenizer(list(seconds), add_special_tokens=False, truncation=False)["input_ids"]
+    bos, eos, pad = tokenizer.bos_token_id, tokenizer.eos_token_id, tokenizer.pad_token_id
+    if bos is None:  # BERT-style vocabularies name them cls / sep
+        bos, eos = tokenizer.cls_token_id, tokenizer.sep_token_id
+    ids_out, mask_out = [], []
+    for a, b in zip(ta, tb):
+        na, nb = truncate_longest_first_2_11(len(a), len(b), max_length - 4)
+        ids = [bos] + list(a[:max(na, 0)]) + [eos, eos] + list(b[:max(nb, 0)]) + [eos]
+        mask = [1] * len(ids)
+        if pad_to_max_length and len(ids) < max_length:
+            mask += [0] * (max_length - len(ids))
+            ids += [pad] * (max_length - len(ids))
+        ids_out.append(ids)
+        mask_out.append(mask)
+    return ids_out, mask_out
 
 
 def collate_tokens(values, pad_idx, eos_idx=None, left_pad=False, move_eos_to_beginning=False):
@@ -73,6 +113,9 @@ class EmDataset(torch.utils.data.Dataset):
         if "Roberta" in self.tokenizer.__class__.__name__ and sample["text"].strip() == "":
             print(f"empty doc title: {sample['title']}")
             sample["text"] = sample["title"]
+        if "Roberta" in self.tokenizer.__class__.__name__:  # the reference's truncation rule, whatever the HF version's is
+            ids, mask = encode_pairs_2_11(self.tokenizer, [normalize(sample["title"].strip())], [sample["text"].strip()], self.max_len, False)
+            return {"input_ids": torch.tensor(ids, dtype=torch.int64), "attention_mask": torch.tensor(mask, dtype=torch.int64)}
         return self.tokenizer(normalize(sample["title"].strip()), text_pair=sample["text"].strip(), max_length=self.max_len,
                               truncation=True, return_tensors="pt")
 

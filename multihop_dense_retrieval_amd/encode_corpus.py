@@ -21,21 +21,90 @@ from .data import EmDataset, em_collate
 from .retriever import RobertaConfig, RobertaCtxEncoder, load_saved, move_to_cuda
 
 
-def predict(model, eval_dataloader, out, row0=0, out_bf16=None):
-    """reference :95-113 -- batches -> model(batch)['embed'] -> rows of `out` (streamed, not torch.cat'ed).
+class _Indexed(torch.utils.data.Dataset):
+    """Items of `dataset[lo:hi]` together with their global row index."""
+
+    def __init__(self, dataset, lo, hi):
+        self.dataset, self.lo, self.hi = dataset, lo, hi
+
+    def __len__(self):
+        return self.hi - self.lo
+
+    def __getitem__(self, i):
+        return self.lo + i, self.dataset[self.lo + i]
+
+
+class LengthBucketCollate:
+    """Collate one WINDOW of tokenised passages into length-homogeneous batches: sort the window by token count, cut it into
+    batches of `batch_size`, em_collate each. Returns [(row indices int64, batch dict)]. Every passage keeps its own output
+    row, so the saved matrix is the reference's; what changes is that a batch's padded width (and with it the encoder's
+    hipGraph shape bucket) follows the length distribution instead of the longest outlier of a random batch."""
+
+    def __init__(self, batch_size):
+        self.batch_size = batch_size
+
+    def __call__(self, samples):
+        order = sorted(range(len(samples)), key=lambda j: (int(samples[j][1]["input_ids"].numel()), samples[j][0]))
+        out = []
+        for s in range(0, len(order), self.batch_size):
+            sel = order[s:s + self.batch_size]
+            out.append((torch.tensor([samples[j][0] for j in sel], dtype=torch.int64), em_collate([samples[j][1] for j in sel])))
+        return out
+
+
+def shard_range(n, world, rank):
+    """Contiguous row block of `rank` (the same rule as index.shard_bounds): [lo, hi)."""
+    per = -(-n // world)
+    return min(n, rank * per), min(n, (rank + 1) * per)
+
+
+def predict(model, eval_dataloader, out, out_bf16=None, to_device=move_to_cuda):
+    """reference :95-113 -- batches -> model(batch)['embed'] -> rows of `out` (streamed into the memory-mapped matrix, not
+    torch.cat'ed in host RAM). The loader yields windows of (row indices, batch) pairs (LengthBucketCollate).
     out_bf16 (optional): a uint16 matrix receiving the same rows rounded to bf16 (round-to-nearest-even bit patterns)."""
     model.eval()
-    at = row0
-    for batch in eval_dataloader:
-        batch_to_feed = move_to_cuda(batch)
-        with torch.no_grad():
-            e = model(batch_to_feed)["embed"]
-            embed = e.cpu().numpy()
-            if out_bf16 is not None:
-                out_bf16[at:at + embed.shape[0]] = e.to(torch.bfloat16).view(torch.int16).cpu().numpy().view(np.uint16)
-        out[at:at + embed.shape[0]] = embed
-        at += embed.shape[0]
-    return at - row0
+    n = 0
+    for window in eval_dataloader:
+        for rows, batch in window:
+            batch_to_feed = to_device(batch)
+            with torch.no_grad():
+                e = model(batch_to_feed)["embed"]
+                embed = e.cpu().numpy()
+                if out_bf16 is not None:
+                    out_bf16[rows.numpy()] = e.to(torch.bfloat16).view(torch.int16).cpu().numpy().view(np.uint16)
+            out[rows.numpy()] = embed
+            n += embed.shape[0]
+    return n
+
+
+def encode_shard(model, dataset, args, rank, world, hidden, barrier=None, to_device=move_to_cuda):
+    """This rank's share of the job (what replaces the reference's DataParallel wrap, :85-89): rows [lo, hi) of the corpus
+    through `model`, written into ONE memory-mapped `<embed_save_path>.npy` shared by all ranks (rank 0 creates it; the
+    barrier orders creation before the first write and the last write before anyone reads). Returns (path, rows written)."""
+    n = len(dataset)
+    lo, hi = shard_range(n, world, rank)
+    window = max(1, int(getattr(args, "length_bucket_window", 1))) * args.predict_batch_size
+    loader = DataLoader(_Indexed(dataset, lo, hi), batch_size=window, collate_fn=LengthBucketCollate(args.predict_batch_size),
+                        pin_memory=torch.cuda.is_available(), num_workers=args.num_workers)
+    path = args.embed_save_path + ".npy"  # np.save appends .npy to the same string that names the id2doc directory (:93)
+    side = args.embed_save_path + ".bf16.npy"
+    if rank == 0:
+        mm = np.lib.format.open_memmap(path, mode="w+", dtype=np.float32, shape=(n, hidden))
+        del mm
+        if args.save_bf16:
+            mm = np.lib.format.open_memmap(side, mode="w+", dtype=np.uint16, shape=(n, hidden))
+            del mm
+    if barrier is not None:
+        barrier()
+    out = np.load(path, mmap_mode="r+")
+    out16 = np.load(side, mmap_mode="r+") if args.save_bf16 else None
+    done = predict(model, loader, out, out_bf16=out16, to_device=to_device)
+    out.flush()
+    if out16 is not None:
+        out16.flush()
+    if barrier is not None:
+        barrier()
+    return path, done
 
 
 def main(argv=None, tokenizer=None):
@@ -68,29 +137,9 @@ def main(argv=None, tokenizer=None):
     model = load_saved(model, args.init_checkpoint, exact=False)
     model.to(torch.device("cuda"))
 
+    barrier = torch.distributed.barrier if world > 1 else None
+    path, _ = encode_shard(model, dataset, args, rank, world, cfg.hidden_size, barrier=barrier)
     n = len(dataset)
-    per = -(-n // world)
-    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
-    loader = DataLoader(torch.utils.data.Subset(dataset, range(lo, hi)), batch_size=args.predict_batch_size, collate_fn=em_collate,
-                        pin_memory=True, num_workers=args.num_workers)
-    path = args.embed_save_path + ".npy"  # np.save appends .npy to the same string that names the id2doc directory (:93)
-    side = args.embed_save_path + ".bf16.npy"
-    if rank == 0:
-        mm = np.lib.format.open_memmap(path, mode="w+", dtype=np.float32, shape=(n, cfg.hidden_size))
-        del mm
-        if args.save_bf16:
-            mm = np.lib.format.open_memmap(side, mode="w+", dtype=np.uint16, shape=(n, cfg.hidden_size))
-            del mm
-    if world > 1:
-        torch.distributed.barrier()
-    out = np.load(path, mmap_mode="r+")
-    out16 = np.load(side, mmap_mode="r+") if args.save_bf16 else None
-    predict(model, loader, out, row0=lo, out_bf16=out16)
-    out.flush()
-    if out16 is not None:
-        out16.flush()
-    if world > 1:
-        torch.distributed.barrier()
     if rank == 0:
         print(torch.Size((n, cfg.hidden_size)))
     return path

@@ -81,11 +81,14 @@ def _load_config(model_name):
 
 def _tokenize(tokenizer, texts, pairs, max_length):
     """`batch_encode_plus(x, max_length=n, pad_to_max_length=True, return_tensors="pt")` of transformers 2.11
-    (eval_mhop_retrieval.py:148,168) in the >=4 spelling: longest-first truncation, right-pad to max_length."""
+    (eval_mhop_retrieval.py:148,168): `<s> q </s>` / `<s> q </s></s> d </s>`, longest-first truncation, right-pad to
+    max_length. Single texts go through the installed tokenizer's own call (identical in every version); pairs through
+    data.encode_pairs_2_11, which keeps the reference's (slow-tokenizer) truncation rule for odd token budgets too."""
     if pairs is None:
         return tokenizer(texts, max_length=max_length, padding="max_length", truncation=True, return_tensors="pt")
-    a, b = [p[0] for p in pairs], [p[1] for p in pairs]
-    return tokenizer(a, b, max_length=max_length, padding="max_length", truncation="longest_first", return_tensors="pt")
+    from .data import encode_pairs_2_11
+    ids, mask = encode_pairs_2_11(tokenizer, [p[0] for p in pairs], [p[1] for p in pairs], max_length, True)
+    return {"input_ids": torch.tensor(ids, dtype=torch.int64), "attention_mask": torch.tensor(mask, dtype=torch.int64)}
 
 
 def load_corpus(corpus_dict, use_store, rank=0, world=1):

@@ -72,3 +72,23 @@ class OracleLib:
 @pytest.fixture(scope="session")
 def oracle():
     return OracleLib()
+
+
+@pytest.fixture(scope="session")
+def tiny_roberta_tokenizer(tmp_path_factory):
+    """A REAL HuggingFace RobertaTokenizer (byte-level BPE) over the tiny vocabulary of tests/golden/tiny_bpe (see
+    make_tiny_bpe.py; the roberta-base files do not exist offline), saved as a model directory and loaded back through
+    AutoTokenizer.from_pretrained(<local dir>) -- the CLIs' own loading path."""
+    import json
+    transformers = pytest.importorskip("transformers")
+    bpe = os.path.join(GOLDEN, "tiny_bpe")
+    with open(os.path.join(bpe, "vocab.json")) as f:
+        vocab = json.load(f)
+    with open(os.path.join(bpe, "merges.txt")) as f:
+        merges = [tuple(ln.split()) for ln in f.read().split("\n") if ln and not ln.startswith("#")]
+    t = transformers.RobertaTokenizer(vocab=vocab, merges=merges)
+    d = tmp_path_factory.mktemp("tiny_roberta")
+    t.save_pretrained(str(d))
+    t2 = transformers.AutoTokenizer.from_pretrained(str(d))
+    assert "Roberta" in t2.__class__.__name__ and (t2.bos_token_id, t2.pad_token_id, t2.eos_token_id) == (0, 1, 2)
+    return t2

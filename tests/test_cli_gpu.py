@@ -1,5 +1,5 @@
-"""GPU (-m gpu): the two drop-in CLIs end to end on a toy corpus with a toy tokenizer (the roberta-base BPE
-files are not available offline): encode_corpus writes <path>.npy + <path>/id2doc.json, eval_mhop_retrieval
+"""GPU (-m gpu): the two drop-in CLIs end to end on a toy corpus with a real HF byte-level BPE tokenizer class over a
+tiny vocabulary (tests/golden/tiny_bpe; the roberta-base BPE files are not available offline): encode_corpus writes <path>.npy + <path>/id2doc.json, eval_mhop_retrieval
 consumes them, and its hop-1/hop-2 decisions equal a plain re-computation with the CPU oracle."""
 import json
 
@@ -12,42 +12,21 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-class RobertaToyTokenizer:
-    """Whitespace 'BPE': <s> a </s></s> b </s>, longest-first truncation, optional max_length padding (pad id 1)."""
-
-    def _ids(self, text):
-        return [3 + (sum(map(ord, w)) % 500) for w in text.split()]
-
-    def _one(self, a, b, max_length):
-        ia, ib = self._ids(a), (self._ids(b) if b is not None else None)
-        budget = max_length - (2 if ib is None else 4)
-        while len(ia) + (len(ib) if ib is not None else 0) > budget:
-            if ib is not None and len(ib) >= len(ia):
-                ib.pop()
-            else:
-                ia.pop()
-        return [0] + ia + [2] + ([2] + ib + [2] if ib is not None else [])
-
-    def __call__(self, a, b=None, text_pair=None, max_length=None, padding=False, truncation=True, return_tensors=None, add_special_tokens=True):
-        if not add_special_tokens:
-            return {"input_ids": self._ids(a)}
-        b = b if b is not None else text_pair
-        single = isinstance(a, str)
-        A = [a] if single else list(a)
-        Bs = [None] * len(A) if b is None else ([b] if single else list(b))
-        rows = [self._one(x, y, max_length) for x, y in zip(A, Bs)]
-        width = max_length if padding == "max_length" else max(map(len, rows))
-        ids = torch.full((len(rows), width), 1, dtype=torch.long)
-        mask = torch.zeros((len(rows), width), dtype=torch.long)
-        for i, r in enumerate(rows):
-            ids[i, :len(r)] = torch.tensor(r)
-            mask[i, :len(r)] = 1
-        return {"input_ids": ids, "attention_mask": mask}
+def encode_np(tok, a, b, max_length, pad):
+    """numpy (ids, mask) of one text / pair under the reference's 2.11 contract (data.encode_pairs_2_11; for a single text the
+    tokenizer's own call)."""
+    from multihop_dense_retrieval_amd import data
+    if b is None:
+        e = tok([a], max_length=max_length, padding="max_length" if pad else False, truncation=True, return_tensors="np")
+        return e["input_ids"].astype(np.int64), e["attention_mask"].astype(np.int64)
+    ids, mask = data.encode_pairs_2_11(tok, [a], [b], max_length, pad)
+    return np.asarray(ids, np.int64), np.asarray(mask, np.int64)
 
 
-def test_encode_corpus_then_eval_mhop(tmp_path, capsys):
+def test_encode_corpus_then_eval_mhop(tmp_path, capsys, tiny_roberta_tokenizer):
     from multihop_dense_retrieval_amd import encode_corpus, eval_mhop_retrieval
-    geom = dict(seeded.TINY, hidden=768, heads=12, ffn=512)  # index dimension must be 768 for the stream kernel
+    tok = tiny_roberta_tokenizer  # a real HF byte-level BPE class (tests/golden/tiny_bpe), not a whitespace stand-in
+    geom = dict(seeded.TINY, hidden=768, heads=12, ffn=512, vocab=max(seeded.TINY["vocab"], len(tok)))  # index dimension must be 768
     sd = seeded.make_state_dict(31, geom)
     import transformers
     cfg_dir = tmp_path / "toy-roberta"
@@ -62,7 +41,6 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys):
     docs[5]["text"] = "  "  # empty passage: title fallback, -inf hop-1 score
     corpus = tmp_path / "corpus.jsonl"
     corpus.write_text("\n".join(json.dumps(d) for d in docs))
-    tok = RobertaToyTokenizer()
     save = tmp_path / "emb"
     path = encode_corpus.main(["--do_predict", "--predict_batch_size", "50", "--model_name", str(cfg_dir), "--predict_file", str(corpus),
                                "--init_checkpoint", str(ckpt), "--embed_save_path", str(save), "--fp16", "--max_c_len", "30",
@@ -74,8 +52,8 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys):
     id2doc = json.load(open(save / "id2doc.json"))
     assert id2doc["5"] == ["T5", "  ", False] and len(id2doc) == 257
     # passage 7 against the numpy restatement of the encoder
-    enc = tok("T7", docs[7]["text"], max_length=30)
-    ref = roberta_oracle.encode(sd, geom, enc["input_ids"].numpy(), enc["attention_mask"].numpy(), np.float64)
+    ids7, mask7 = encode_np(tok, "T7", docs[7]["text"], 30, False)
+    ref = roberta_oracle.encode(sd, geom, ids7, mask7, np.float64)
     assert np.abs(xb[7:8] - ref).max() < 1e-2
 
     qs = [{"_id": f"q{i}", "question": " ".join(rng.choice(words, 6)) + "?", "answer": ["a"], "sp": [f"T{i}", f"T{i + 1}"],
@@ -144,8 +122,8 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys):
     with pytest.raises(SystemExit):
         eval_mhop_fever.main([str(data_f), path, str(save / "id2doc.json"), str(ckpt), "--model-name", "bert-base-uncased"], tokenizer=tok)
     # hop-1 decision of question 0 equals an oracle recomputation from the saved index
-    enc = tok(qs[0]["question"][:-1], max_length=12, padding="max_length")
-    qv = roberta_oracle.encode(sd, geom, enc["input_ids"].numpy(), enc["attention_mask"].numpy(), np.float64)
+    ids0, mask0 = encode_np(tok, qs[0]["question"][:-1], None, 12, True)
+    qv = roberta_oracle.encode(sd, geom, ids0, mask0, np.float64)
     scores = (xb.astype(np.float64) @ qv[0])
     best3 = set(np.argsort(-scores)[:3].tolist())
     got_hop1 = {c[0]["title"] for c in rec["candidate_chains"]}

@@ -1,0 +1,200 @@
+"""Tokenizer fidelity with a REAL HuggingFace byte-level BPE tokenizer class (RobertaTokenizer over the tiny vocabulary of
+tests/golden/tiny_bpe, see make_tiny_bpe.py): the three places where the product path talks to a tokenizer.
+
+  a8/a14  eval_mhop_retrieval._tokenize           == tokenizer.batch_encode_plus(x, max_length=n, pad_to_max_length=True) of
+                                                     transformers 2.11 (/root/reference/scripts/eval/eval_mhop_retrieval.py:148,168)
+  (f)1    arena.TokenArena + mdr_assemble_hop2    == the same pair encoding, token for token (prefix-space behaviour of
+                                                     byte-level BPE in pair position included)
+  a21     data.EmDataset.__getitem__              == tokenizer.encode_plus(title, text_pair=text, max_length=n)
+                                                     (/root/reference/mdr/retrieval/data/encode_datasets.py:95)
+
+The 2.11 contract is restated as a literal loop (`contract_pair`): `<s> A </s></s> B </s>`, `truncate_sequences` with
+strategy 'longest_first' = pop one token at a time from the longer sequence (from B on a tie), right-pad with the pad id
+to max_length. The installed tokenizer class is checked against that loop first, so the loop is pinned by HF itself and
+not only by our reading of it.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+transformers = pytest.importorskip("transformers")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+QUESTIONS = [
+    "Who directed the film that starred the actor born in 1950",
+    "What is the population of the city where the author of Les Misérables was born",
+    "Which band released the album",
+    "Zürich",
+    "a",
+    "Which band released the album recorded at the studio founded by the producer of Thriller and what is the population of the city "
+    "where the author of Les Misérables was born and who directed the film that starred the actor born in 1950 in Lyon near the river bank",
+]
+DOCS = {
+    "0": {"title": "Paris", "text": "Paris is the capital of France. It lies on the Seine, north of Orléans."},
+    "1": {"title": "London 2012", "text": "The 2012 Summer Olympics were held in London; the stadium seats 80,000 people."},
+    "2": {"title": "Empty passage title", "text": "   "},
+    "3": {"title": "Long", "text": "Multi-hop dense retrieval answers open-domain questions by reading two passages in a row. " * 12},
+    "4": {"title": "x", "text": "q"},
+    "5": {"title": "Unseen bytes", "text": "naïve café ☃ 日本 tab\there"},
+    "6": {"title": "Leading space", "text": " The quick brown fox"},
+}
+
+
+@pytest.fixture(scope="module")
+def tok(tiny_roberta_tokenizer):
+    return tiny_roberta_tokenizer
+
+
+def bare(tok, text):
+    return tok(text, add_special_tokens=False)["input_ids"]
+
+
+def contract_single(tok, text, n):
+    a = bare(tok, text)[: n - 2]
+    ids = [0] + a + [2]
+    return ids + [1] * (n - len(ids)), [1] * len(ids) + [0] * (n - len(ids))
+
+
+def contract_pair(tok, a_text, b_text, n, pad=True):
+    a, b = list(bare(tok, a_text)), list(bare(tok, b_text))
+    while len(a) + len(b) + 4 > n:  # transformers 2.11 truncate_sequences('longest_first'), one token at a time
+        if len(a) > len(b):
+            a.pop()
+        else:
+            b.pop()
+    ids = [0] + a + [2, 2] + b + [2]
+    if not pad:
+        return ids, [1] * len(ids)
+    return ids + [1] * (n - len(ids)), [1] * len(ids) + [0] * (n - len(ids))
+
+
+def test_tokenize_single_is_the_2_11_contract(tok):
+    from multihop_dense_retrieval_amd.eval_mhop_retrieval import _tokenize
+    for n in (8, 16, 70):
+        enc = _tokenize(tok, QUESTIONS, None, n)
+        assert enc["input_ids"].shape == (len(QUESTIONS), n) and enc["input_ids"].dtype == torch.int64
+        for i, q in enumerate(QUESTIONS):
+            ids, mask = contract_single(tok, q, n)
+            assert enc["input_ids"][i].tolist() == ids, (n, q)
+            assert enc["attention_mask"][i].tolist() == mask
+
+
+@pytest.mark.parametrize("n", [12, 33, 64, 350])
+def test_tokenize_pairs_is_the_2_11_contract(tok, n):
+    from multihop_dense_retrieval_amd import mhop
+    from multihop_dense_retrieval_amd.eval_mhop_retrieval import _tokenize
+    I = np.array([[0, 1], [2, 3], [4, 5], [6, 0], [3, 3], [1, 2]])
+    D = np.zeros(I.shape, np.float32)
+    pairs = mhop.build_hop2_pairs(QUESTIONS, D, I, DOCS, roberta=True)
+    assert D[1, 0] == -np.inf and np.isfinite(D[0]).all()  # the empty-text rule (:162-165) fired for doc "2" only
+    enc = _tokenize(tok, None, pairs, n)
+    for r, (q, d) in enumerate(pairs):
+        ids, mask = contract_pair(tok, q, d, n)
+        assert enc["input_ids"][r].tolist() == ids, (n, r)
+        assert enc["attention_mask"][r].tolist() == mask
+
+
+def test_closed_form_of_the_2_11_pop_loop():
+    from multihop_dense_retrieval_amd.data import truncate_longest_first_2_11
+    for la in range(0, 40):
+        for lb in range(0, 40):
+            for budget in range(0, 40):
+                a, b = la, lb
+                while a + b > budget:  # transformers 2.11 tokenization_utils.truncate_sequences, 'longest_first'
+                    if a > b:
+                        a -= 1
+                    else:
+                        b -= 1
+                assert truncate_longest_first_2_11(la, lb, budget) == (a, b), (la, lb, budget)
+
+
+def test_installed_hf_pair_truncation_against_the_2_11_rule(tok):
+    """What the INSTALLED tokenizer does with the same request. Even token budgets (the CLIs' defaults: 350 - 4, 300 - 4):
+    identical to the reference's rule, so HF itself pins `truncate_longest_first_2_11`. Odd budgets with both sides cut:
+    the Rust implementation hands the extra token to the longer (on a tie: second) sequence, the 2.11 loop keeps it in
+    the first -- which is why the product path applies the reference's rule itself instead of passing truncation= through."""
+    from multihop_dense_retrieval_amd.data import truncate_longest_first_2_11
+    word = " a"
+    assert len(bare(tok, word * 7)) == 7
+    differ = 0
+    for la, lb in [(20, 30), (30, 20), (10, 40), (40, 10), (25, 25), (15, 14), (15, 16), (3, 50), (50, 3), (1, 1)]:
+        for n in (12, 13, 32, 33, 64, 65):
+            e = tok(word * la, word * lb, max_length=n, truncation="longest_first")["input_ids"]
+            na = e.index(2) - 1
+            nb = len(e) - na - 4
+            ra, rb = truncate_longest_first_2_11(la, lb, n - 4)
+            assert na + nb == ra + rb
+            if (n - 4) % 2 == 0 or min(la, lb) * 2 <= n - 4:
+                assert (na, nb) == (ra, rb), (la, lb, n)
+            else:
+                assert abs(na - ra) <= 1
+                differ += (na, nb) != (ra, rb)
+    assert differ > 0  # the divergence is real with this transformers version; if it disappears, the note above is stale
+
+
+def test_second_sequence_is_tokenised_like_a_standalone_text(tok):
+    """Byte-level BPE adds no prefix space in pair position (add_prefix_space=False): the arena may therefore tokenise
+    every passage ONCE, standalone, and splice it behind any question."""
+    for d in DOCS.values():
+        text = d["text"] if d["text"].strip() else d["title"]
+        enc = tok("Which band", text)["input_ids"]
+        a = bare(tok, "Which band")
+        assert enc == [0] + a + [2, 2] + bare(tok, text) + [2]
+    assert bare(tok, " The quick") != bare(tok, "The quick")  # ... and a real leading space is kept, not normalised away
+
+
+def test_em_dataset_item_is_encode_plus_of_title_and_text(tok, tmp_path):
+    from multihop_dense_retrieval_amd import data
+    corpus = tmp_path / "corpus.jsonl"
+    docs = [DOCS[str(i)] for i in range(len(DOCS))] + [{"title": "Orléans café", "text": " padded text  "}]
+    corpus.write_text("".join(json.dumps(d) + "\n" for d in docs))
+    for n in (10, 40, 300):
+        ds = data.EmDataset(tok, str(corpus), 70, n, False, str(tmp_path / "save"))
+        assert len(ds) == len(docs)
+        for i, d in enumerate(docs):
+            item = ds[i]
+            text = d["text"].strip() if d["text"].strip() else d["title"]  # encode_datasets.py:89-91 (Roberta: empty text -> title)
+            ids, mask = contract_pair(tok, data.normalize(d["title"].strip()), text.strip(), n, pad=False)
+            assert item["input_ids"].view(-1).tolist() == ids, (n, i)
+            assert item["attention_mask"].view(-1).tolist() == mask
+    saved = json.load(open(tmp_path / "save" / "id2doc.json"))
+    assert saved["0"] == [docs[0]["title"], docs[0]["text"], False]  # encode_datasets.py:76-80
+
+
+def test_arena_holds_the_standalone_tokens(tok):
+    from multihop_dense_retrieval_amd.arena import TokenArena
+    ar = TokenArena.from_corpus(DOCS, tok, roberta=True, max_tokens=350)
+    off = ar.offsets.tolist()
+    for i in range(len(DOCS)):
+        d = DOCS[str(i)]
+        text = d["text"] if d["text"].strip() else d["title"]
+        assert ar.tokens[off[i]:off[i + 1]].tolist() == bare(tok, text)[:350]
+    assert ar.empty.tolist() == [0, 0, 1, 0, 0, 0, 0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,beam", [(12, 1), (33, 2), (64, 3), (350, 2)])
+def test_device_assembly_equals_the_hf_pair_encoding(tok, n, beam):
+    """mdr_assemble_hop2 over the token arena == tokenizer(q, d, truncation='longest_first', padding='max_length') for every
+    (question, passage) pair, incl. the empty-text passage (title + -inf hop-1 score) and truncation on either side."""
+    from multihop_dense_retrieval_amd import mhop
+    from multihop_dense_retrieval_amd.arena import TokenArena
+    from multihop_dense_retrieval_amd.eval_mhop_retrieval import _tokenize
+    ar = TokenArena.from_corpus(DOCS, tok, roberta=True, max_tokens=350).to(torch.device("cuda"))
+    rng = np.random.RandomState(n)
+    I = rng.randint(0, len(DOCS), size=(len(QUESTIONS), beam))
+    I[1, 0] = 2  # the empty passage
+    D = rng.rand(*I.shape).astype(np.float32)
+    qfull = _tokenize(tok, QUESTIONS, None, 350)  # the CLI's own call (questions without the hop-1 length cap)
+    Dd = torch.from_numpy(D).cuda()
+    ids, mask = ar.assemble_hop2(qfull["input_ids"].cuda(), qfull["attention_mask"].cuda(), torch.from_numpy(I).cuda(), Dd, n)
+    Dh = D.copy()
+    pairs = mhop.build_hop2_pairs(QUESTIONS, Dh, I, DOCS, roberta=True)
+    enc = _tokenize(tok, None, pairs, n)
+    assert torch.equal(ids.cpu(), enc["input_ids"])
+    assert torch.equal(mask.cpu(), enc["attention_mask"])
+    assert np.array_equal(Dd.cpu().numpy(), Dh)  # -inf exactly where the host rule puts it
