@@ -46,6 +46,7 @@ _SIGNATURES = {
     "mdr_index_search_workspace_bytes": (_c.c_size_t, [_c.c_void_p, _c.c_int, _c.c_int]),
     "mdr_index_search": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                     _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "mdr_index_search_telemetry": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.POINTER(_c.c_int64), _c.c_void_p]),
     "mdr_index_set_variant": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "mdr_index_last_kernel": (_c.c_char_p, [_c.c_void_p]),
     "mdr_topk_merge": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p]),

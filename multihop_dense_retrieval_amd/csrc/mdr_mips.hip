@@ -157,18 +157,69 @@ __global__ void __launch_bounds__(256) row_norm2_max_kernel(const T* __restrict_
     if (lane == 0 && s == s && __float_as_int(s) > flags[2]) atomicMax(flags + 2, __float_as_int(s));  // pre-check: one hot word
 }
 
-// one wave per query: bound[q] = c * |q| * max_row|x| + eps  (0 for padding queries)
-__global__ void __launch_bounds__(256) query_bound_kernel(const float* __restrict__ q, int nq, int nq_pad, int d, const int* __restrict__ flags,
-                                                          float c, float* __restrict__ bound) {
+// Query preparation, one wave per query row (rows >= nq are zero padding). Every query is PRE-SCALED by a power of two
+//     s = 2^e,  max_i |q_i| / s in [0.5, 1)            (s = 1 for an all-zero row)
+// before it is rounded to fp16 / bf16: ranking is invariant to a positive query scale, the division is exact, and the
+// MFMA operands are then always in fp16's well-conditioned range whatever the caller's magnitudes are (|q_i| > 65504 would
+// otherwise round to inf, tiny queries into subnormals where the relative bound below does not hold). Writes
+//   qhi / qlo   fragment-tiled fp16 (hi, lo) pair of q / s (BF: one plane of bf16 bit patterns)
+//   qscale[q]   s (the exact stream kernel multiplies its scores back; the screen kernels' scores stay internal, their
+//               survivors are re-scored from the caller's fp32 query)
+//   bound[q]    B = c * |q / s| * max_row|x| * 1.0001 + 1e-4  >=  |(q/s).x - fp16(q/s).fp16(x)|  for every stored row x:
+//               c covers the two operand roundings (2^-10; bf16 rows: the query's 2^-9 only) plus fp32 accumulation; since
+//               |q/s| >= 0.5 the relative term also dominates the absolute error of elements that fall into fp16's subnormal
+//               range (2^-25 each), for which the 1e-4 is a second belt.
+// flags[1] is raised for a non-finite query element (results for that query are unspecified, as with FAISS).
+template <bool BF>
+__global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restrict__ q, int nq, int nq_pad, int d, int* __restrict__ flags, float c,
+                                                           char* __restrict__ qhi, char* __restrict__ qlo, float* __restrict__ bound,
+                                                           float* __restrict__ qscale) {
     const int lane = threadIdx.x & 63;
-    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= nq_pad) return;
-    float s = 0.f;
+    const int nkb = d >> 5, ngrp = d >> 3;
+    float mx = 0.f, ss = 0.f;
+    bool bad = false;
     if (i < nq)
-        for (int c = lane; c < d; c += 64) { float x = q[(size_t)i * d + c]; s += x * x; }
+        for (int col = lane; col < d; col += 64) {
+            const float x = q[(size_t)i * d + col];
+            if (!(fabsf(x) <= 3.0e38f)) bad = true;
+            mx = fmaxf(mx, fabsf(x));
+            ss = fmaf(x, x, ss);
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) bound[i] = i < nq ? c * sqrtf(s) * sqrtf(__int_as_float(flags[2])) * 1.0001f + 1e-4f : 0.f;
+    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); ss += __shfl_xor(ss, o); }
+    if (__ballot(bad) && lane == 0) atomicOr(flags + 1, 1);
+    int e = 0;
+    float sc = 1.f;
+    if (mx > 0.f && mx <= 3.0e38f) { (void)frexpf(mx, &e); sc = ldexpf(1.f, e); }
+    const float inv = 1.f / sc;  // exact: a power of two
+    for (int g = lane; g < ngrp; g += 64) {
+        half8 h, l;
+        ushort8 hb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = i < nq ? q[(size_t)i * d + g * 8 + j] * inv : 0.f;
+            if (BF) {
+                hb[j] = f32_to_bf16_rne(x);
+            } else {
+                const _Float16 hh = (_Float16)x;
+                h[j] = hh;
+                l[j] = (_Float16)((x - (float)hh) * kLoScale);
+            }
+        }
+        const size_t off = frag_offset(i, g * 8, nkb);
+        if (BF) {
+            *(ushort8*)(qhi + off) = hb;
+        } else {
+            *(half8*)(qhi + off) = h;
+            *(half8*)(qlo + off) = l;
+        }
+    }
+    if (lane == 0) {
+        qscale[i] = sc;
+        bound[i] = i < nq ? c * (sqrtf(ss) * inv) * sqrtf(__int_as_float(flags[2])) * 1.0001f + 1e-4f : 0.f;
+    }
 }
 
 __device__ inline int block_sum_256(int v, int* red) {
@@ -279,7 +330,7 @@ template <int NKB, int KMODE>  // KMODE 0: k == 1 (register argmax)   1: 2 <= k 
 __global__ void __launch_bounds__(512, 2)
 mips_stream_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, long long n_rows, int n_rb, const char* __restrict__ Qhi,
                    const char* __restrict__ Qlo, int nq, u64* __restrict__ best, u64* __restrict__ cand, int* __restrict__ cand_cnt,
-                   u64* __restrict__ cand_kth, int k, const int* __restrict__ run_if) {
+                   u64* __restrict__ cand_kth, int k, const int* __restrict__ run_if, const float* __restrict__ qscale) {
     if (run_if && *run_if == 0) return;  // speculative screen pass succeeded: nothing to do
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int RB_BYTES = NKB * 2 * kFragBytes;
@@ -391,7 +442,10 @@ mips_stream_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, l
     }
 
     if (KMODE == 0) {
-        u64 key = make_key(best_s, best_row);
+        // back to the caller's scale (queries were pre-scaled by a power of two: exact, order-preserving). KMODE 1 lists stay
+        // in the scaled domain and merge_lists_kernel multiplies at the output.
+        const float sc = q_valid ? qscale[qlocal] : 1.f;
+        u64 key = make_key(best_s > -FLT_MAX ? best_s * sc : best_s, best_row);
         // lanes l, l^16, l^32, l^48 hold the same query
         u64 o = __shfl_xor(key, 16);
         key = o > key ? o : key;
@@ -848,7 +902,7 @@ merge_screenk_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_
     int total = 0;
     for (int w = tid; w < G; w += 256) total += cand_cnt[(size_t)w * kStreamQ + ql];
     total = block_sum_256(total, red);
-    if (tid == 0) s_n = 0;
+    if (tid == 0) { s_n = 0; atomicAdd(overflow + 1, total); }  // telemetry: candidates the main pass handed over (sctl[1])
     __syncthreads();
     const int kk = total < k ? total : k;
     if (kk == 0) {
@@ -989,7 +1043,8 @@ __global__ void finalize_top1_kernel(const u64* __restrict__ best, int nq, float
 // general k: merge G per-workgroup lists of one query group. One 256-thread block per query.
 __global__ void __launch_bounds__(256)
 merge_lists_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_cnt, const u64* __restrict__ cand_kth, int G, int qcap,
-                   int cap, int k, float* __restrict__ D, long long* __restrict__ I, long long id_offset, const int* __restrict__ run_if) {
+                   int cap, int k, float* __restrict__ D, long long* __restrict__ I, long long id_offset, const int* __restrict__ run_if,
+                   const float* __restrict__ qscale /* per query of this group, or null: scores are in the caller's scale already */) {
     __shared__ u64 keys[kMergeLds];
     if (run_if && *run_if == 0) return;
     __shared__ u64 sel[kKMax];
@@ -1078,7 +1133,7 @@ merge_lists_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_cn
             u64 me = sel[i];
             int rank = 0;
             for (int j = 0; j < kk; ++j) rank += sel[j] > me;
-            Dq[rank] = key_score(me);
+            Dq[rank] = key_score(me) * (qscale ? qscale[ql] : 1.f);
             Iq[rank] = id_offset + (long long)key_row(me);
         } else {
             Dq[i] = -FLT_MAX;
@@ -1215,7 +1270,7 @@ struct SearchPlan {
     int Gx;   // workgroups of the exact stream kernel (== G on the stream path; the fallback behind the screen kernels)
     int Gg;   // workgroups of the generic kernel (when its lists are needed)
     bool lists_stream, lists_generic;
-    size_t off_qhi, off_qlo, off_bound, off_best, off_gmax, off_scand, off_sctl, off_cand, off_cnt, off_kth, total;
+    size_t off_qhi, off_qlo, off_bound, off_qscale, off_best, off_gmax, off_scand, off_sctl, off_cand, off_cnt, off_kth, total;
 };
 
 SearchPlan make_plan(const mdr_index* h, int nq, int k) {
@@ -1243,7 +1298,8 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
     p.off_qhi = take(frag ? nq_pad * h->d * 2 : 0);
     p.off_qlo = take(frag && !is_bf16(h) ? nq_pad * h->d * 2 : 0);
-    p.off_bound = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
+    p.off_bound = take(frag ? nq_pad * 4 : 0);
+    p.off_qscale = take(frag ? nq_pad * 4 : 0);
     p.off_best = take((size_t)(nq > 0 ? nq : 1) * 8);
     p.off_gmax = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
     // k == 1: one private list per wave; k > 1: the [G][kStreamQ] sample maxima
@@ -1279,7 +1335,7 @@ int run_generic(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
         hipLaunchKernelGGL((mips_generic_kernel<BF>), dim3(p.Gg), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, (long long)h->ntotal, n_rb, h->nkb,
                            q_dev + (size_t)q0 * h->d, nqg, cand, cnt, kth, k, run_if);
         hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.Gg, kGenericQ, kGenericCap,
-                           k, D_dev + (size_t)q0 * k, I_dev + (size_t)q0 * k, id_offset, run_if);
+                           k, D_dev + (size_t)q0 * k, I_dev + (size_t)q0 * k, id_offset, run_if, (const float*)nullptr);
         MDR_HIP_TRY(hipGetLastError());
     }
     return MDR_OK;
@@ -1301,12 +1357,8 @@ int run_screen(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, 
     const int nq_pad = ngroups * kStreamQ;
     const int n_sb = (int)((h->ntotal + 31) / 32);
     const size_t qgroup_bytes = (size_t)kStreamQ * h->d * 2;
-    // |q.x - qh.xh| <= c |q| max|x|: fp16 rounding of both operands (2^-10) or bf16 rounding of q only (2^-9; the
-    // stored rows ARE the bf16 values), plus fp32 accumulation slack
-    const float c = BF ? 2.2e-3f : 1.2e-3f;
     MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
     MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
-    hipLaunchKernelGGL(query_bound_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)h->flags, c, bound);
     for (int gi = 0; gi < ngroups; ++gi) {
         const int nqg = nq - gi * kStreamQ < kStreamQ ? nq - gi * kStreamQ : kStreamQ;
         const char* qg = qhi + gi * qgroup_bytes;
@@ -1343,9 +1395,7 @@ int run_screenk(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
     const int nq_pad = ngroups * kStreamQ;
     const int n_sb = (int)((h->ntotal + 31) / 32);
     const size_t qgroup_bytes = (size_t)kStreamQ * h->d * 2;
-    const float c = BF ? 2.2e-3f : 1.2e-3f;  // see run_screen
     MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
-    hipLaunchKernelGGL(query_bound_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)h->flags, c, bound);
     for (int gi = 0; gi < ngroups; ++gi) {
         const int nqg = nq - gi * kStreamQ < kStreamQ ? nq - gi * kStreamQ : kStreamQ;
         const char* qg = qhi + gi * qgroup_bytes;
@@ -1528,8 +1578,20 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
     u64* best = (u64*)(ws + p.off_best);
     char* qhi = ws + p.off_qhi;
     char* qlo = ws + p.off_qlo;
-    rc = launch_convert(bf, q_dev, (long long)nq, (long long)ngroups * kStreamQ, h->d, 0, qhi, qlo, h->flags + 1, st);
-    if (rc) return rc;
+    float* qscale = (float*)(ws + p.off_qscale);
+    {
+        // |q.x - qh.xh| <= c |q| max|x|: fp16 rounding of both operands (2^-10) or bf16 rounding of q only (2^-9; the
+        // stored rows ARE the bf16 values), plus fp32 accumulation slack
+        const float c = bf ? 2.2e-3f : 1.2e-3f;
+        const int nq_pad = ngroups * kStreamQ;
+        float* bound = (float*)(ws + p.off_bound);
+        MDR_HIP_TRY(hipMemsetAsync(h->flags + 1, 0, sizeof(int), st));  // "a query of THIS call was non-finite" (telemetry)
+        if (bf)
+            hipLaunchKernelGGL((prep_queries_kernel<true>), dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, h->flags, c, qhi, qlo, bound, qscale);
+        else
+            hipLaunchKernelGGL((prep_queries_kernel<false>), dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, h->flags, c, qhi, qlo, bound, qscale);
+        MDR_HIP_TRY(hipGetLastError());
+    }
 
     if (k == 1) {
         MDR_HIP_TRY(hipMemsetAsync(best, 0, (size_t)nq * 8, st));
@@ -1550,7 +1612,8 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
                 const int nqg = nq - gi * kStreamQ < kStreamQ ? nq - gi * kStreamQ : kStreamQ;
                 hipLaunchKernelGGL((mips_stream_kernel<NKB, 0>), dim3(Gx), dim3(512), 3 * rb_bytes, st, (const char*)h->hi, (const char*)h->lo,
                                    (long long)h->ntotal, n_rb, (const char*)(qhi + gi * qgroup_bytes), (const char*)(qlo + gi * qgroup_bytes), nqg,
-                                   best + (size_t)gi * kStreamQ, (u64*)nullptr, (int*)nullptr, (u64*)nullptr, 1, run_if);
+                                   best + (size_t)gi * kStreamQ, (u64*)nullptr, (int*)nullptr, (u64*)nullptr, 1, run_if,
+                                   (const float*)(qscale + (size_t)gi * kStreamQ));
                 MDR_HIP_TRY(hipGetLastError());
             }
         }
@@ -1586,12 +1649,50 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
         MDR_HIP_TRY(hipMemsetAsync(kth, 0, (size_t)p.Gx * kStreamQ * 8, st));
         hipLaunchKernelGGL((mips_stream_kernel<NKB, 1>), dim3(p.Gx), dim3(512), lds_bytes, st, (const char*)h->hi, (const char*)h->lo, (long long)h->ntotal,
                            n_rb, (const char*)(qhi + gi * qgroup_bytes), (const char*)(qlo + gi * qgroup_bytes), nqg, (u64*)nullptr, cand, cnt, kth, k,
-                           run_if);
+                           run_if, (const float*)(qscale + (size_t)gi * kStreamQ));
         MDR_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.Gx, kStreamQ, kStreamCap, k,
-                           D_dev + (size_t)gi * kStreamQ * k, I_ll + (size_t)gi * kStreamQ * k, (long long)id_offset, run_if);
+                           D_dev + (size_t)gi * kStreamQ * k, I_ll + (size_t)gi * kStreamQ * k, (long long)id_offset, run_if,
+                           (const float*)(qscale + (size_t)gi * kStreamQ));
         MDR_HIP_TRY(hipGetLastError());
     }
+    return MDR_OK;
+}
+
+int mdr_index_search_telemetry(const mdr_index* h, int nq, int k, const void* workspace_dev, int64_t* out4_host, void* stream) {
+    MDR_REQUIRE(h && workspace_dev && out4_host, "NULL argument");
+    MDR_REQUIRE(nq >= 1 && k >= 1 && k <= kKMax, "bad shape");
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const SearchPlan p = make_plan(h, nq, k);
+    const char* ws = (const char*)(((uintptr_t)workspace_dev + 255) & ~(uintptr_t)255);
+    out4_host[0] = out4_host[1] = out4_host[2] = 0;
+    out4_host[3] = p.path;
+    int flags[4] = {0, 0, 0, 0};
+    MDR_HIP_TRY(hipMemcpyAsync(flags, h->flags, sizeof(flags), hipMemcpyDeviceToHost, st));
+    MDR_HIP_TRY(hipStreamSynchronize(st));
+    out4_host[2] = flags[1];
+    if (p.path != PATH_SCREEN) return MDR_OK;
+    int overflow = 0;
+    MDR_HIP_TRY(hipMemcpyAsync(&overflow, ws + p.off_sctl, sizeof(int), hipMemcpyDeviceToHost, st));
+    long long total = 0;
+    if (k == 1) {  // per-wave list lengths of the last query group
+        const size_t n_cnt = (size_t)p.G * 8;
+        int* cnt = new (std::nothrow) int[n_cnt];
+        MDR_REQUIRE(cnt != nullptr, "out of host memory");
+        hipError_t e = hipMemcpyAsync(cnt, ws + p.off_sctl + 256, n_cnt * sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        for (size_t i = 0; i < n_cnt; ++i) total += cnt[i];
+        delete[] cnt;
+        if (e != hipSuccess) return set_error(MDR_E_HIP, "telemetry copy failed: %s", hipGetErrorString(e));
+    } else {  // merge_screenk_kernel adds every query's union size to sctl[1]
+        int t = 0;
+        MDR_HIP_TRY(hipMemcpyAsync(&t, ws + p.off_sctl + sizeof(int), sizeof(int), hipMemcpyDeviceToHost, st));
+        MDR_HIP_TRY(hipStreamSynchronize(st));
+        total = t;
+    }
+    out4_host[0] = overflow;
+    out4_host[1] = total;
     return MDR_OK;
 }
 

@@ -112,6 +112,13 @@ class IndexFlatIP:
         """Queries one pass over the shard serves (a search with nq queries reads the corpus ceil(nq / this) times)."""
         return int(_lib.lib().mdr_index_queries_per_pass(self._h, int(k)))
 
+    def telemetry(self, nq, k):
+        """Test hook (synchronises): {"fallback", "candidates", "bad_query", "path"} of the last search of this shape."""
+        out = (ctypes.c_int64 * 4)()
+        _lib.check(_lib.lib().mdr_index_search_telemetry(self._h, int(nq), int(k), ctypes.c_void_p(self._ws.data_ptr()), out,
+                                                         _lib.current_stream_ptr(self.device)))
+        return {"fallback": int(out[0]), "candidates": int(out[1]), "bad_query": int(out[2]), "path": int(out[3])}
+
     def set_variant(self, v):
         """Test hook: 0 auto, 1 generic fp32 kernel, 2 exact 3-MFMA stream kernel, 3 screen + refine (k == 1)."""
         _lib.check(_lib.lib().mdr_index_set_variant(self._h, int(v)))

@@ -95,16 +95,17 @@ def test_encode_args_flags():
 
 def test_em_dataset_writes_id2doc_and_pairs_title_text(tmp_path):
     class RobertaToy:  # class name contains "Roberta" -> empty text falls back to the title (encode_datasets.py:89-91)
-        def __call__(self, a, text_pair=None, max_length=None, truncation=None, return_tensors=None):
-            ids = [0] + [3 + len(w) for w in a.split()] + [2, 2] + [3 + len(w) for w in text_pair.split()] + [2]
-            ids = ids[:max_length]
-            return {"input_ids": torch.tensor([ids]), "attention_mask": torch.ones(1, len(ids), dtype=torch.long)}
+        bos_token_id, eos_token_id, pad_token_id = 0, 2, 1
+
+        def __call__(self, texts, add_special_tokens=True, truncation=False):  # the surface data.encode_pairs_2_11 uses: bare BPE of a list
+            assert add_special_tokens is False and truncation is False
+            return {"input_ids": [[3 + len(w) for w in t.split()] for t in texts]}
     corpus = tmp_path / "c.jsonl"
     corpus.write_text("\n".join(json.dumps(d) for d in [{"title": "A b", "text": "x yy zzz"}, {"title": "Empty", "text": " "},
                                                         {"title": "I", "text": "t", "intro": True}]))
     ds = data.EmDataset(RobertaToy(), str(corpus), 20, 6, False, str(tmp_path / "emb"))
     assert json.load(open(tmp_path / "emb" / "id2doc.json")) == {"0": ["A b", "x yy zzz", False], "1": ["Empty", " ", False], "2": ["I", "t", True]}
-    assert len(ds) == 3 and ds[0]["input_ids"].shape[1] == 6  # truncated to max_c_len
+    assert len(ds) == 3 and ds[0]["input_ids"].tolist() == [[0, 4, 2, 2, 4, 2]]  # longest-first truncation to max_c_len = 6 (title "A b" and text lose one token each... the pop loop: 2+3 -> 1+1)
     assert ds[1]["input_ids"].tolist() == [[0, 8, 2, 2, 8, 2]]  # title used as text
     b = data.em_collate([ds[0], ds[2]])
     assert b["input_ids"].shape == (2, 6) and b["input_mask"].sum().item() == 6 + ds[2]["input_ids"].shape[1]
