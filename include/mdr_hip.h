@@ -129,6 +129,11 @@ typedef struct mdr_encoder mdr_encoder;
 typedef struct mdr_encoder_config {
     int vocab, hidden, layers, heads, ffn, max_pos, pad_id;
     float ln_eps;
+    /* 1: LayerNorm outputs are kept in fp32 for the residual adds, only the copy that feeds the next Linear is rounded to
+     *    fp16 -- the apex-O1 regime the reference runs under (eval_mhop_retrieval.py:88-89: LayerNorm is an fp32 op, the
+     *    residual add promotes to fp32). 0: the residual stream is the fp16 copy (less HBM traffic, one more rounding per
+     *    LayerNorm). Results differ inside fp16-operand noise; DESIGN.md §4 has the measured cost and error of both. */
+    int residual_fp32;
 } mdr_encoder_config;
 
 /* One fp32 tensor of the q_encoder.pt schema, Linear weights [out, in]. */

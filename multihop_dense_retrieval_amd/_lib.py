@@ -22,7 +22,8 @@ class MdrError(RuntimeError):
 
 class EncoderConfig(ctypes.Structure):
     _fields_ = [("vocab", ctypes.c_int), ("hidden", ctypes.c_int), ("layers", ctypes.c_int), ("heads", ctypes.c_int),
-                ("ffn", ctypes.c_int), ("max_pos", ctypes.c_int), ("pad_id", ctypes.c_int), ("ln_eps", ctypes.c_float)]
+                ("ffn", ctypes.c_int), ("max_pos", ctypes.c_int), ("pad_id", ctypes.c_int), ("ln_eps", ctypes.c_float),
+                ("residual_fp32", ctypes.c_int)]
 
 
 class Tensor(ctypes.Structure):

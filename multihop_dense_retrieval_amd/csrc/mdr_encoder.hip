@@ -124,7 +124,7 @@ constexpr int kMaxPerLane = 16;  // hidden <= 1024
 __global__ void __launch_bounds__(256)
 embed_ln_kernel(const long long* __restrict__ ids, const int* __restrict__ tok_src, const int* __restrict__ tok_pid, const int* __restrict__ total,
                 const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type0, const float* __restrict__ g,
-                const float* __restrict__ bta, int H, int vocab, int max_pos, float eps, _Float16* __restrict__ out) {
+                const float* __restrict__ bta, int H, int vocab, int max_pos, float eps, _Float16* __restrict__ out, float* __restrict__ out32) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= *total) return;
@@ -148,23 +148,26 @@ embed_ln_kernel(const long long* __restrict__ ids, const int* __restrict__ tok_s
     const float rstd = rsqrtf(wave_sum(v) / H + eps);
 #pragma unroll
     for (int i = 0; i < kMaxPerLane; ++i)
-        if (i < n) { int e = lane + 64 * i; out[(size_t)t * H + e] = (_Float16)((x[i] - mu) * rstd * g[e] + bta[e]); }
+        if (i < n) {
+            const int e = lane + 64 * i;
+            const float y = (x[i] - mu) * rstd * g[e] + bta[e];
+            out[(size_t)t * H + e] = (_Float16)y;
+            if (out32) out32[(size_t)t * H + e] = y;  // fp32 residual stream (mdr_encoder_config.residual_fp32)
+        }
 }
 
-// fp32 rows -> LayerNorm -> fp16 (out16) and/or fp32 (out32); one wave per row, 16-byte loads (H % 256 == 0 fast path)
+// fp32 rows (+ residual) -> LayerNorm -> fp16 (out16: the next GEMM's operand) and/or fp32 (out32: the residual stream in
+// residual_fp32 mode, or the final embedding); one wave per row, 16-byte loads (H % 256 == 0 fast path).
+// `res16` / `res32` (at most one): residual added before normalising, when the producing GEMM left it out. out32 may alias
+// res32 (a wave reads its whole row before it writes it).
 __global__ void __launch_bounds__(256)
-layernorm_kernel(const float* __restrict__ in, const _Float16* __restrict__ res, int rows_cap, const int* __restrict__ rows_dev, int H,
-                 const float* __restrict__ g, const float* __restrict__ bta, float eps, _Float16* __restrict__ out16, float* __restrict__ out32,
-                 int in_f16) {
-    // `res` (optional): fp16 residual added before normalising (when the producing GEMM left it out).
-    // in_f16: the rows at `in` are fp16 (the large-M GEMMs write their pre-LayerNorm sums in half precision: the stores
-    // are what those GEMMs wait for, and the reference's apex-O1 Linear outputs are fp16 as well).
+layernorm_kernel(const float* __restrict__ in, const _Float16* __restrict__ res16, const float* res32, int rows_cap, const int* __restrict__ rows_dev,
+                 int H, const float* __restrict__ g, const float* __restrict__ bta, float eps, _Float16* __restrict__ out16, float* out32) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rows = rows_dev ? min(*rows_dev, rows_cap) : rows_cap;
     if (t >= rows) return;
     const float* r = in + (size_t)t * H;
-    const _Float16* r16 = (const _Float16*)in + (size_t)t * H;
     if ((H & 255) == 0) {
         const int n4 = H >> 8;  // float4 per lane (<= 4)
         f32x4 x[4];
@@ -172,18 +175,13 @@ layernorm_kernel(const float* __restrict__ in, const _Float16* __restrict__ res,
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < n4) {
-                if (in_f16) {
-                    const half4 h4 = *(const half4*)(r16 + (lane + 64 * i) * 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) x[i][j] = (float)h4[j];
-                } else {
-                    x[i] = *(const f32x4*)(r + (lane + 64 * i) * 4);
-                }
-                if (res) {
-                    const half4 r4 = *(const half4*)(res + (size_t)t * H + (lane + 64 * i) * 4);
+                x[i] = *(const f32x4*)(r + (lane + 64 * i) * 4);
+                if (res16) {
+                    const half4 r4 = *(const half4*)(res16 + (size_t)t * H + (lane + 64 * i) * 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) x[i][j] += (float)r4[j];
                 }
+                if (res32) x[i] += *(const f32x4*)(res32 + (size_t)t * H + (lane + 64 * i) * 4);
                 s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
             }
         const float mu = wave_sum(s) / H;
@@ -218,7 +216,10 @@ layernorm_kernel(const float* __restrict__ in, const _Float16* __restrict__ res,
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxPerLane; ++i)
-        if (i < n) { x[i] = (in_f16 ? (float)r16[lane + 64 * i] : r[lane + 64 * i]) + (res ? (float)res[(size_t)t * H + lane + 64 * i] : 0.f); s += x[i]; }
+        if (i < n) {
+            x[i] = r[lane + 64 * i] + (res16 ? (float)res16[(size_t)t * H + lane + 64 * i] : 0.f) + (res32 ? res32[(size_t)t * H + lane + 64 * i] : 0.f);
+            s += x[i];
+        }
     const float mu = wave_sum(s) / H;
     float v = 0.f;
 #pragma unroll
@@ -236,11 +237,13 @@ layernorm_kernel(const float* __restrict__ in, const _Float16* __restrict__ res,
 }
 
 // first token of every sequence -> dense [B, H] fp16
-__global__ void gather_cls_kernel(const _Float16* __restrict__ h, const int* __restrict__ cu, int B, int H, _Float16* __restrict__ out) {
+__global__ void gather_cls_kernel(const _Float16* __restrict__ h, const float* __restrict__ h32, const int* __restrict__ cu, int B, int H,
+                                  _Float16* __restrict__ out, float* __restrict__ out32) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * H) return;
     int b = i / H, e = i - b * H;
     out[i] = h[(size_t)cu[b] * H + e];
+    if (h32) out32[i] = h32[(size_t)cu[b] * H + e];
 }
 
 __global__ void f32_to_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, long long n) {
@@ -1192,7 +1195,7 @@ namespace {
 struct Workspace {
     int *lens, *cu, *total, *tok_src, *tok_pid;
     _Float16 *h16, *qkv, *ctx, *ffn, *cls16;
-    float *pre, *clspre;
+    float *pre, *clspre, *h32, *cls32;  // h32 / cls32: the fp32 residual stream (residual_fp32 mode only)
     size_t bytes;
 };
 
@@ -1213,6 +1216,8 @@ Workspace carve(const mdr_encoder_config& c, int B, int L, char* base) {
     w.pre = (float*)take(T * c.hidden * 4);
     w.cls16 = (_Float16*)take((size_t)B * c.hidden * 2);
     w.clspre = (float*)take((size_t)B * c.hidden * 4);
+    w.h32 = c.residual_fp32 ? (float*)take(T * c.hidden * 4) : nullptr;
+    w.cls32 = c.residual_fp32 ? (float*)take((size_t)B * c.hidden * 4) : nullptr;
     w.bytes = o + 256;
     return w;
 }
@@ -1262,8 +1267,7 @@ int launch_gemm_big(const _Float16* A, int lda, const _Float16* W, const float* 
 // *res_added tells the caller whether the residual went into the output (else the following LayerNorm adds it).
 template <int EPI>
 int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
-                const _Float16* res, int ldr, int M_est, int num_cus, hipStream_t st, bool* res_added = nullptr, int force = -1,
-                bool* out_f16 = nullptr) {
+                const _Float16* res, int ldr, int M_est, int num_cus, hipStream_t st, bool* res_added = nullptr, int force = -1) {
     // experiment knob: 1 small, 2 mid, 3 big tiles; 4 persistent 256x128 / 6 persistent 256x256 for the large-M calls (the others keep the heuristic)
     static int env_sel = getenv("MDR_GEMM_CFG") ? atoi(getenv("MDR_GEMM_CFG")) : 0;
     int sel = force >= 0 ? force : env_sel;
@@ -1273,13 +1277,6 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
     if ((sel == 4 || sel == 6 || (sel == 0 && p_tiles >= (long long)num_cus * 3 / 2)) && N % 128 == 0 && N <= kPersistBiasMax) {
         if (res_added) *res_added = false;
         else if (EPI == EPI_BIAS_RES_F32) return set_error(MDR_E_STATE, "large-M GEMM with a residual needs the caller to take the residual (res_added)");
-        // opt-in (MDR_PRE16=1): -3 % hop-2 encode time, but +5e-3 max / +8e-4 mean embedding error and the large-batch path
-        // is then no longer bit-identical to the small-batch one (tests/test_encoder_gpu.py::test_large_batch_...)
-        static const bool pre16_ok = getenv("MDR_PRE16") && atoi(getenv("MDR_PRE16")) == 1;
-        if (EPI == EPI_BIAS_RES_F32 && out_f16 && pre16_ok && N % 256 == 0) {  // pre-LayerNorm sums leave in fp16 (see layernorm_kernel)
-            *out_f16 = true;
-            return launch_gemm_big<EPI_BIAS_F16>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
-        }
         constexpr int E = EPI == EPI_BIAS_RES_F32 ? EPI_BIAS_F32 : EPI;
         // Both kernels are bound by the bytes a CU moves over its L2 path, loads AND stores (~20 B/clk/CU measured; skipping
         // the stores made the K = 768 GEMMs 25-30 % faster, deferring them did not): cost = rounds x (tile inputs + outputs).
@@ -1505,30 +1502,43 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
     hipLaunchKernelGGL(enc_lens_kernel, dim3((B + 3) / 4), dim3(256), 0, st, mask, B, L, w.lens);
     hipLaunchKernelGGL(enc_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)w.lens, B, w.cu, w.total);
     hipLaunchKernelGGL(enc_scatter_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, mask, B, L, c.pad_id, (const int*)w.cu, w.tok_src, w.tok_pid);
+    // Residual stream. residual_fp32 = 0: LayerNorm outputs live as fp16 only (GEMM operand AND residual). residual_fp32 = 1:
+    // the apex-O1 regime of the reference -- LayerNorm outputs stay fp32 (w.h32) for the residual adds, and only the copy
+    // that feeds the next Linear is rounded to fp16. In that mode no GEMM epilogue adds the (fp16) residual: every
+    // LayerNorm call takes it from w.h32 and refreshes w.h32 in place.
+    const bool r32 = c.residual_fp32 != 0;
     hipLaunchKernelGGL(embed_ln_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, ids, (const int*)w.tok_src, (const int*)w.tok_pid, (const int*)w.total,
                        (const float*)h->word, (const float*)h->pos, (const float*)h->type0, (const float*)h->emb_g, (const float*)h->emb_b, H, c.vocab,
-                       c.max_pos, c.ln_eps, w.h16);
+                       c.max_pos, c.ln_eps, w.h16, w.h32);
     MDR_HIP_TRY(hipGetLastError());
     int rc;
+    // y = LayerNorm(gemm_out + residual) for `rows` rows: one place that knows where the residual comes from
+    auto post_ln = [&](const float* pre, bool res_in_gemm, const _Float16* res16, float* res32, int rows_cap, const int* rows_dev, const float* g_,
+                       const float* b_, _Float16* out16, float* out32) {
+        hipLaunchKernelGGL(layernorm_kernel, dim3((rows_cap + 3) / 4), dim3(256), 0, st, pre, (const _Float16*)(r32 || res_in_gemm ? nullptr : res16),
+                           (const float*)(r32 ? res32 : nullptr), rows_cap, rows_dev, H, g_, b_, c.ln_eps, out16, (float*)(r32 ? out32 : nullptr));
+    };
     for (int i = 0; i < c.layers; ++i) {
         const mdr_encoder::Layer& Ly = h->layers[i];
         rc = launch_gemm<EPI_BIAS_F16>(w.h16, H, Ly.wqkv, Ly.bqkv, Tcap, w.total, 3 * H, H, w.qkv, 3 * H, nullptr, 0, Test, ncu, st);
         if (rc) return rc;
         if (i + 1 == c.layers) {
             // ---- last layer: everything after the K/V projection only for the CLS rows ([B, H] instead of [T, H]) ----
-            hipLaunchKernelGGL(gather_cls_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, (const _Float16*)w.h16, (const int*)w.cu, B, H, w.cls16);
+            hipLaunchKernelGGL(gather_cls_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, (const _Float16*)w.h16, (const float*)w.h32, (const int*)w.cu, B, H,
+                               w.cls16, w.cls32);
             hipLaunchKernelGGL(attention_cls_kernel, dim3(c.heads, B), dim3(64), 0, st, (const _Float16*)w.qkv, (const int*)w.cu, H, w.ctx);
             MDR_HIP_TRY(hipGetLastError());
-            rc = launch_gemm<EPI_BIAS_RES_F32>(w.ctx, H, Ly.wo, Ly.bo, B, nullptr, H, H, w.clspre, H, w.cls16, H, B, ncu, st);
+            bool res_in = true;
+            if (r32) rc = launch_gemm<EPI_BIAS_F32>(w.ctx, H, Ly.wo, Ly.bo, B, nullptr, H, H, w.clspre, H, nullptr, 0, B, ncu, st);
+            else rc = launch_gemm<EPI_BIAS_RES_F32>(w.ctx, H, Ly.wo, Ly.bo, B, nullptr, H, H, w.clspre, H, w.cls16, H, B, ncu, st, &res_in);
             if (rc) return rc;
-            hipLaunchKernelGGL(layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, (const _Float16*)nullptr, B, (const int*)nullptr,
-                               H, (const float*)Ly.ln1_g, (const float*)Ly.ln1_b, c.ln_eps, w.cls16, (float*)nullptr, 0);
+            post_ln(w.clspre, res_in, w.cls16, w.cls32, B, nullptr, Ly.ln1_g, Ly.ln1_b, w.cls16, w.cls32);
             rc = launch_gemm<EPI_BIAS_GELU_F16>(w.cls16, H, Ly.w1, Ly.b1, B, nullptr, F, H, w.ffn, F, nullptr, 0, B, ncu, st);
             if (rc) return rc;
-            rc = launch_gemm<EPI_BIAS_RES_F32>(w.ffn, F, Ly.w2, Ly.b2, B, nullptr, H, F, w.clspre, H, w.cls16, H, B, ncu, st);
+            if (r32) rc = launch_gemm<EPI_BIAS_F32>(w.ffn, F, Ly.w2, Ly.b2, B, nullptr, H, F, w.clspre, H, nullptr, 0, B, ncu, st);
+            else rc = launch_gemm<EPI_BIAS_RES_F32>(w.ffn, F, Ly.w2, Ly.b2, B, nullptr, H, F, w.clspre, H, w.cls16, H, B, ncu, st, &res_in);
             if (rc) return rc;
-            hipLaunchKernelGGL(layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, (const _Float16*)nullptr, B, (const int*)nullptr,
-                               H, (const float*)Ly.ln2_g, (const float*)Ly.ln2_b, c.ln_eps, w.cls16, (float*)nullptr, 0);
+            post_ln(w.clspre, res_in, w.cls16, w.cls32, B, nullptr, Ly.ln2_g, Ly.ln2_b, w.cls16, w.cls32);
             MDR_HIP_TRY(hipGetLastError());
             break;
         }
@@ -1540,24 +1550,23 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
         else if (L <= 384) rc = launch_attention<24>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         else rc = launch_attention<32>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         if (rc) return rc;
-        bool res_in = true, pre16 = false;
-        rc = launch_gemm<EPI_BIAS_RES_F32>(w.ctx, H, Ly.wo, Ly.bo, Tcap, w.total, H, H, w.pre, H, w.h16, H, Test, ncu, st, &res_in, -1, &pre16);
+        bool res_in = true;
+        if (r32) rc = launch_gemm<EPI_BIAS_F32>(w.ctx, H, Ly.wo, Ly.bo, Tcap, w.total, H, H, w.pre, H, nullptr, 0, Test, ncu, st);
+        else rc = launch_gemm<EPI_BIAS_RES_F32>(w.ctx, H, Ly.wo, Ly.bo, Tcap, w.total, H, H, w.pre, H, w.h16, H, Test, ncu, st, &res_in);
         if (rc) return rc;
-        hipLaunchKernelGGL(layernorm_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, (const float*)w.pre, (const _Float16*)(res_in ? nullptr : w.h16), Tcap,
-                           (const int*)w.total, H, (const float*)Ly.ln1_g, (const float*)Ly.ln1_b, c.ln_eps, w.h16, (float*)nullptr, pre16 ? 1 : 0);
+        post_ln(w.pre, res_in, w.h16, w.h32, Tcap, w.total, Ly.ln1_g, Ly.ln1_b, w.h16, w.h32);
         rc = launch_gemm<EPI_BIAS_GELU_F16>(w.h16, H, Ly.w1, Ly.b1, Tcap, w.total, F, H, w.ffn, F, nullptr, 0, Test, ncu, st);
         if (rc) return rc;
-        pre16 = false;
-        rc = launch_gemm<EPI_BIAS_RES_F32>(w.ffn, F, Ly.w2, Ly.b2, Tcap, w.total, H, F, w.pre, H, w.h16, H, Test, ncu, st, &res_in, -1, &pre16);
+        if (r32) rc = launch_gemm<EPI_BIAS_F32>(w.ffn, F, Ly.w2, Ly.b2, Tcap, w.total, H, F, w.pre, H, nullptr, 0, Test, ncu, st);
+        else rc = launch_gemm<EPI_BIAS_RES_F32>(w.ffn, F, Ly.w2, Ly.b2, Tcap, w.total, H, F, w.pre, H, w.h16, H, Test, ncu, st, &res_in);
         if (rc) return rc;
-        hipLaunchKernelGGL(layernorm_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, (const float*)w.pre, (const _Float16*)(res_in ? nullptr : w.h16), Tcap,
-                           (const int*)w.total, H, (const float*)Ly.ln2_g, (const float*)Ly.ln2_b, c.ln_eps, w.h16, (float*)nullptr, pre16 ? 1 : 0);
+        post_ln(w.pre, res_in, w.h16, w.h32, Tcap, w.total, Ly.ln2_g, Ly.ln2_b, w.h16, w.h32);
         MDR_HIP_TRY(hipGetLastError());
     }
     rc = launch_gemm<EPI_BIAS_F32>(w.cls16, H, h->wproj, h->bproj, B, nullptr, H, H, w.clspre, H, nullptr, 0, B, ncu, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, (const _Float16*)nullptr, B, (const int*)nullptr, H, (const float*)h->lnp_g,
-                       (const float*)h->lnp_b, c.ln_eps, (_Float16*)nullptr, out_dev, 0);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, (const _Float16*)nullptr, (const float*)nullptr, B,
+                       (const int*)nullptr, H, (const float*)h->lnp_g, (const float*)h->lnp_b, c.ln_eps, (_Float16*)nullptr, out_dev);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }

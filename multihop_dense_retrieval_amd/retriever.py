@@ -73,6 +73,7 @@ class _HipRobertaEncoder:
     SURVEY.md §8a row a23)."""
 
     MAX_TOKENS_PER_CALL = 1 << 17  # workspace bound: larger batches are encoded in slices
+    RESIDUAL_FP32_DEFAULT = False
 
     def __init__(self, config, args=None):
         self.config = config
@@ -86,6 +87,9 @@ class _HipRobertaEncoder:
         self.graph_captures = 0
         self.graph_replays = 0
         self.use_graphs = True
+        # apex-O1-faithful fp32 residual stream (mdr_encoder_config.residual_fp32); MDR_RESIDUAL_FP32=0/1 overrides the default for
+        # measurements before the weights are uploaded
+        self.residual_fp32 = bool(int(os.environ.get("MDR_RESIDUAL_FP32", "1" if self.RESIDUAL_FP32_DEFAULT else "0")))
         self.device = None
         self.training = False
 
@@ -221,7 +225,7 @@ class _HipRobertaEncoder:
         sd = self._pending
         cfg = _lib.EncoderConfig(self.config.vocab_size, self.config.hidden_size, self.config.num_hidden_layers, self.config.num_attention_heads,
                                  self.config.intermediate_size, self.config.max_position_embeddings, self.config.pad_token_id,
-                                 float(self.config.layer_norm_eps))
+                                 float(self.config.layer_norm_eps), int(self.residual_fp32))
         names = [k for k in sd if "pooler" not in k]  # the pooler is never evaluated (`[0]` = sequence output)
         on_dev = all(sd[k].is_cuda for k in names)
         keep = []

@@ -13,14 +13,19 @@ from oracle import roberta_oracle, seeded
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-TOL = {"tiny": (8e-3, 1.5e-3), "base": (2e-2, 3e-3)}
+# measured (round 2): tiny 3.0e-3 / 6.6e-4, base 6.9e-3 / 1.4e-3 with the fp16 residual stream and 5.6e-3 / 1.4e-3 with the
+# fp32 one (mdr_encoder_config.residual_fp32) -- the mean does not move: the error is the fp16 rounding of the GEMM operands
+# (inherent to the reference's apex-O1 regime), amplified by the seeded weights' O(1) sub-layer outputs (oracle/seeded.py).
+TOL = {"tiny": (6e-3, 1.2e-3), "base": (1.2e-2, 2e-3)}
 
 
-def build(geom, seed, cls=None):
+def build(geom, seed, cls=None, residual_fp32=None):
     from multihop_dense_retrieval_amd import retriever
     cfg = retriever.RobertaConfig(vocab_size=geom["vocab"], hidden_size=geom["hidden"], num_hidden_layers=geom["layers"],
                                   num_attention_heads=geom["heads"], intermediate_size=geom["ffn"])
     m = (cls or retriever.RobertaRetriever)(cfg, None)
+    if residual_fp32 is not None:
+        m.residual_fp32 = residual_fp32
     sd = seeded.make_state_dict(seed, geom)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return m.to("cuda").eval(), sd
@@ -39,6 +44,17 @@ def test_encode_q_matches_reference(models, golden, tag, name):
     assert out.dtype == torch.float32 and out.shape == g[f"{name}.embed"].shape
     err = np.abs(out.cpu().numpy() - g[f"{name}.embed"])
     print(f"encoder {tag}.{name}: max abs err {err.max():.3e} mean {err.mean():.3e}")
+    assert err.max() <= TOL[tag][0] and err.mean() <= TOL[tag][1]
+
+
+@pytest.mark.parametrize("tag,name", [("tiny", "qsp"), ("base", "q"), ("base", "qsp")])
+def test_fp32_residual_stream_mode_matches_reference(golden, tag, name):
+    """mdr_encoder_config.residual_fp32 = 1: LayerNorm outputs stay fp32 for the residual adds (the reference's apex-O1 regime)."""
+    g = golden(f"encoder_{tag}.npz")
+    m, _ = build(seeded.TINY if tag == "tiny" else seeded.ROBERTA_BASE, 11 if tag == "tiny" else 7, residual_fp32=True)
+    out = m.encode_q(torch.from_numpy(g[f"{name}.ids"]).cuda(), torch.from_numpy(g[f"{name}.mask"]).cuda(), None)
+    err = np.abs(out.cpu().numpy() - g[f"{name}.embed"])
+    print(f"encoder {tag}.{name} (fp32 residual): max abs err {err.max():.3e} mean {err.mean():.3e}")
     assert err.max() <= TOL[tag][0] and err.mean() <= TOL[tag][1]
 
 
@@ -108,9 +124,7 @@ def test_errors(models):
 def test_large_batch_kernels_agree_with_small_batch_path(models):
     """The retrieval loop's hop-2 batches (>= 16 k tokens) run on the persistent 256x256 GEMMs; the golden fixtures only
     reach the small-batch kernels. Every GEMM flavour accumulates K in the same order in fp32, so the same sequences
-    encoded 4 at a time (the golden-tested path) give the SAME embeddings (observed bit-identical; bar 1e-6). With the
-    opt-in MDR_PRE16=1 (fp16 pre-LayerNorm sums) the bar is fp16 noise: max 1e-2, mean 1.5e-3."""
-    import os
+    encoded 4 at a time (the golden-tested path) give the SAME embeddings (observed bit-identical; bar 1e-6)."""
     m, _ = models["base"]
     B, L = 80, 320
     g = torch.Generator(device="cuda").manual_seed(21)
@@ -126,7 +140,4 @@ def test_large_batch_kernels_agree_with_small_batch_path(models):
     err = (big - small).abs()
     print(f"large-batch vs small-batch path: max {err.max().item():.3e} mean {err.mean().item():.3e}")
     assert bool(torch.isfinite(big).all())
-    if os.environ.get("MDR_PRE16") == "1":
-        assert err.max().item() <= 1e-2 and err.mean().item() <= 1.5e-3
-    else:
-        assert err.max().item() <= 1e-6
+    assert err.max().item() <= 1e-6
