@@ -646,7 +646,9 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
 // its MFMAs whichever of DMA / MFMA / LDS reads was removed -- the barrier skeleton itself; removed.
 using GemmB2 = GemmCfg<256, 256, 2, 4, 2>;
 
-template <int EPI>
+// ABL (measurement only, results are wrong for ABL != 0): 1 = no DMA after the prologue, 2 = no LDS fragment reads, 3 = no MFMAs,
+// 4 = no epilogue stores -- which of the CU's pipes the K-loop is waiting for (scripts/gpu_gemm_bench.py, MDR_GEMM_ABL).
+template <int EPI, int ABL = 0>
 __global__ void __launch_bounds__(512)
 gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M_cap,
                 const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo) {
@@ -693,7 +695,9 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
         w_off = (unsigned)(n0 + ld_row) * (unsigned)K + (unsigned)ld_chunk;
     };
     // piece c (0..7) of the loader's K-tile: 0-3 = A rows 64c.., 4-7 = W rows 64(c-4)..
+    bool dma_on = true;
     auto issue_piece = [&](int c) __attribute__((always_inline)) {
+        if (ABL == 1 && !dma_on) return;
         char* slot = lds + (ld_T & 1) * C::STAGE_BYTES;
         const int k0 = ld_kt * BK;
         const _Float16* src = c < 4 ? A + (a_off[c] + (unsigned)k0) : W + (w_off + (unsigned)(64 * (c - 4) * K + k0));
@@ -718,17 +722,24 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
     next_ktile();
 #pragma unroll
     for (int c = 0; c < 2; ++c) issue_piece(c);  // "sub-phase 4 of step -1"
+    dma_on = false;
 
     f32x4 acc[8][4];
     half8 wf0[4], wf1[4], af_a[4], af_b[4];
+    if (ABL == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wf0[q] = wf1[q] = af_a[q] = af_b[q] = (half8){1, 1, 1, 1, 1, 1, 1, 1};
+    }
     // 16 MFMAs (4 m-fragments from mbase x 4 n-fragments) with DMA pieces pc, pc+1 pinned after the 2nd and 4th group
     auto sub_phase = [&](auto zero_c, int mbase, const half8* wfr, const half8* afr, int pc) __attribute__((always_inline)) {
         constexpr bool Z = decltype(zero_c)::value;  // first K-tile of an output tile: accumulate onto 0
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < 4; ++n) {
+                if (ABL == 3) { asm volatile("" ::"v"(wfr[n]), "v"(afr[q])); if (Z) acc[mbase + q][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }
                 acc[mbase + q][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfr[n], afr[q], Z ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mbase + q][n], 0, 0, 0);
+            }
             if (q == 1) issue_piece(pc);
             if (q == 3) issue_piece(pc + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -744,27 +755,27 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
         asm volatile("" ::: "memory");
         // reads for sub-phases 1 and 2
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wf0[q] = *(const half8*)(slot + w_rd + q * 16 * 128 + sw0);
+        for (int q = 0; q < 4; ++q) if (ABL != 2) wf0[q] = *(const half8*)(slot + w_rd + q * 16 * 128 + sw0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) af_a[q] = *(const half8*)(slot + a_rd + q * 16 * 128 + sw0);
+        for (int q = 0; q < 4; ++q) if (ABL != 2) af_a[q] = *(const half8*)(slot + a_rd + q * 16 * 128 + sw0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) af_b[q] = *(const half8*)(slot + a_rd + (4 + q) * 16 * 128 + sw0);
+        for (int q = 0; q < 4; ++q) if (ABL != 2) af_b[q] = *(const half8*)(slot + a_rd + (4 + q) * 16 * 128 + sw0);
         __builtin_amdgcn_sched_barrier(0);
         // ---- sub-phase 1: k-half 0, m-fragments 0-3; pieces 2,3 of the loader's K-tile (T+1)
         if (first) sub_phase(std::true_type{}, 0, wf0, af_a, 2);
         else sub_phase(std::false_type{}, 0, wf0, af_a, 2);
         // reads for sub-phase 3 (k-half 1): W fragments, A fragments 0-3 into the registers sub-phase 1 just released
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wf1[q] = *(const half8*)(slot + w_rd + q * 16 * 128 + sw1);
+        for (int q = 0; q < 4; ++q) if (ABL != 2) wf1[q] = *(const half8*)(slot + w_rd + q * 16 * 128 + sw1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) af_a[q] = *(const half8*)(slot + a_rd + q * 16 * 128 + sw1);
+        for (int q = 0; q < 4; ++q) if (ABL != 2) af_a[q] = *(const half8*)(slot + a_rd + q * 16 * 128 + sw1);
         __builtin_amdgcn_sched_barrier(0);
         // ---- sub-phase 2: k-half 0, m-fragments 4-7; pieces 4,5
         if (first) sub_phase(std::true_type{}, 4, wf0, af_b, 4);
         else sub_phase(std::false_type{}, 4, wf0, af_b, 4);
         // reads for sub-phase 4: the LAST reads of this slot
 #pragma unroll
-        for (int q = 0; q < 4; ++q) af_b[q] = *(const half8*)(slot + a_rd + (4 + q) * 16 * 128 + sw1);
+        for (int q = 0; q < 4; ++q) if (ABL != 2) af_b[q] = *(const half8*)(slot + a_rd + (4 + q) * 16 * 128 + sw1);
         __builtin_amdgcn_sched_barrier(0);
         // ---- sub-phase 3: k-half 1, m-fragments 0-3; pieces 6,7 complete K-tile T+1
         sub_phase(std::false_type{}, 0, wf1, af_a, 6);
@@ -818,6 +829,7 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
                         const int r = rd_row + 8 * half;
                         const f32x4 val = *(const f32x4*)(scr + r * 128 + ((rd_chunk ^ (r & 7)) << 4));
                         const int m = mrow + r;
+                        if (ABL == 4) { asm volatile("" ::"v"(val)); continue; }
                         if (m < M) {
                             if constexpr (F16OUT) *(f32x4*)((_Float16*)out + (size_t)m * ldo + n0 + wc * 64 + rd_chunk * 8) = val;
                             else *(f32x4*)((float*)out + (size_t)m * ldo + n0 + wc * 64 + hf * 32 + rd_chunk * 4) = val;
@@ -1256,8 +1268,19 @@ template <int EPI>
 int launch_gemm_big(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
                     int M_est, int num_cus, hipStream_t st) {
     constexpr int lds = GemmB2::LDS_BYTES + kPersistBiasMax * 4 + 8 * 2048;  // slots + bias + per-wave epilogue scratch
-    { int rc_ = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI>, lds); if (rc_) return rc_; }
     const int grid = num_cus / 8 * 8;
+    const char* abl_env = getenv("MDR_GEMM_ABL");  // measurement knob (wrong results): see gemm_big_kernel
+    const int abl = abl_env ? atoi(abl_env) : 0;
+#define MDR_BIG_ABL(A_)                                                                                                          \
+    if (abl == A_) {                                                                                                              \
+        { int rc_ = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI, A_>, lds); if (rc_) return rc_; }                         \
+        hipLaunchKernelGGL((gemm_big_kernel<EPI, A_>), dim3(grid), dim3(512), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo); \
+        MDR_HIP_TRY(hipGetLastError());                                                                                           \
+        return MDR_OK;                                                                                                            \
+    }
+    MDR_BIG_ABL(1) MDR_BIG_ABL(2) MDR_BIG_ABL(3) MDR_BIG_ABL(4)
+#undef MDR_BIG_ABL
+    { int rc_ = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI>, lds); if (rc_) return rc_; }
     hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(grid), dim3(512), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
