@@ -274,8 +274,9 @@ def main():
     # ---- roofline of the dominant MIPS kernel: PHYSICAL HBM bytes / HIP-event time of each search call ----------------
     calls = pipe.search_calls()  # [(ms, nq)] of every timed local search (rank-local)
     shard_bytes = local.stream_bytes()  # N_pad * d * 4 (fp32 index) or * 2 (bf16): the corpus read once
-    qpp = local.queries_per_pass(args.beam)
-    passes = [max(1, -(-nq // qpp)) for _, nq in calls]
+    qpps = [local.queries_per_pass(nq, args.beam) for _, nq in calls]
+    passes = [max(1, -(-nq // qpp)) for (_, nq), qpp in zip(calls, qpps)]
+    qpp = max(qpps) if qpps else 0
     tot_ms = sum(ms for ms, _ in calls)
     alg_bytes = float(sum(shard_bytes * p for p in passes))
     kname = local.last_kernel()

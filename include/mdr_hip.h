@@ -77,9 +77,9 @@ int mdr_index_dim(const mdr_index* h);
 /* bytes of HBM one search call streams for the corpus (= ntotal_padded * d * bytes/elem) */
 int64_t mdr_index_stream_bytes(const mdr_index* h);
 
-/* Queries one corpus pass of mdr_index_search serves for this k (a call with nq queries streams the shard
- * ceil(nq / this) times): the accounting bench.py's roofline uses. */
-int mdr_index_queries_per_pass(const mdr_index* h, int k);
+/* Queries one corpus pass of mdr_index_search(nq, k) serves (the call streams the shard ceil(nq / this) times): the
+ * accounting bench.py's roofline uses. 128 for up to 128 queries, 256 beyond (32 queries per wave). */
+int mdr_index_queries_per_pass(const mdr_index* h, int nq, int k);
 
 /* Workspace one search call needs (device memory, 256-byte aligned, contents don't persist). */
 size_t mdr_index_search_workspace_bytes(const mdr_index* h, int nq, int k);

@@ -43,7 +43,7 @@ _SIGNATURES = {
     "mdr_index_ntotal": (_c.c_int64, [_c.c_void_p]),
     "mdr_index_dim": (_c.c_int, [_c.c_void_p]),
     "mdr_index_stream_bytes": (_c.c_int64, [_c.c_void_p]),
-    "mdr_index_queries_per_pass": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "mdr_index_queries_per_pass": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
     "mdr_index_search_workspace_bytes": (_c.c_size_t, [_c.c_void_p, _c.c_int, _c.c_int]),
     "mdr_index_search": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                     _c.c_void_p, _c.c_size_t, _c.c_void_p]),

@@ -598,24 +598,32 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
         const f32x4 s0 = a00 + a01, s1 = a10 + a11;
         const unsigned row0 = (unsigned)(b + it * sG) * 32u + sub_row;
         const float cut = known - band2;  // a row below this cannot beat the row that produced `known`
+        // Fast path (almost every stage): the super-block lies inside the corpus and no score reaches the cut -> 7 max
+        // operations and ONE ballot instead of 8 compare / ballot / branch sequences.
+        const bool whole = (long long)(b + it * sG) * 32 + 32 <= n_rows;  // wave-uniform
+        const float m8 = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        if (whole && (MODE != 1 || __ballot(q_valid && m8 >= cut) == 0ull)) {
+            if (q_valid) hmax = fmaxf(hmax, m8);
+        } else {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float sc = h ? s1[r] : s0[r];
-                const unsigned row = row0 + 16u * h + r;
-                const bool ok = (long long)row < n_rows && q_valid;
-                if (ok) hmax = fmaxf(hmax, sc);
-                if (MODE == 1) {
-                    const bool hit = ok && sc >= cut;
-                    const u64 m = __ballot(hit);
-                    if (m) {  // wave-uniform
-                        const int slot = my_cnt + __popcll(m & lt);
-                        if (hit && slot < kWaveCandCap) my_list[slot] = ((u64)(unsigned)(q_base + qlocal) << 32) | row;
-                        my_cnt += __popcll(m);
+                for (int r = 0; r < 4; ++r) {
+                    const float sc = h ? s1[r] : s0[r];
+                    const unsigned row = row0 + 16u * h + r;
+                    const bool ok = (long long)row < n_rows && q_valid;
+                    if (ok) hmax = fmaxf(hmax, sc);
+                    if (MODE == 1) {
+                        const bool hit = ok && sc >= cut;
+                        const u64 m = __ballot(hit);
+                        if (m) {  // wave-uniform
+                            const int slot = my_cnt + __popcll(m & lt);
+                            if (hit && slot < kWaveCandCap) my_list[slot] = ((u64)(unsigned)(q_base + qlocal) << 32) | row;
+                            my_cnt += __popcll(m);
+                        }
                     }
                 }
-            }
+        }
         if (MODE == 1) {  // share the maximum between the 4 lanes of a query
             float hm = fmaxf(hmax, __shfl_xor(hmax, 16));
             hm = fmaxf(hm, __shfl_xor(hm, 32));
@@ -630,6 +638,158 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
         float hm = fmaxf(hmax, __shfl_xor(hmax, 16));
         hm = fmaxf(hm, __shfl_xor(hm, 32));
         if (lane < 16 && q_valid) gmax[(size_t)b * kStreamQ + qlocal] = hm > -FLT_MAX ? ord32(hm) : 0u;
+    } else if (lane == 0) {
+        cand_cnt[b * 8 + wave] = my_cnt < kWaveCandCap ? my_cnt : kWaveCandCap;
+        if (my_cnt > kWaveCandCap) *overflow = 1;
+    }
+}
+
+// ---- the screen kernel with 32 queries per wave (256 per pass): v_mfma_f32_32x32x16 -------------------------------------
+// Same streaming skeleton, same bound, same candidate lists and the same two passes (MODE 0 sample / MODE 1 main, MODE 2
+// per-workgroup maxima for k > 1) as mips_screen_kernel; what changes is the tile: one 32x32x16 MFMA multiplies the WHOLE
+// 32-row super-block with 32 queries, so a wave keeps 32 queries resident (48 K-slices x 4 VGPRs = 192 registers) and a
+// corpus pass serves 256 queries instead of 128. Used when a call brings more than 128 queries (hop 2 at beam >= 2, the
+// weak-scaling bench, and the hop-2 + next hop-1 searches of the pipelined loop): half the corpus passes.
+// The stored corpus layout (16-row fragment blocks for 16x16x32) is read with a different address pattern: K-slice s of a
+// 32-row super-block, lane (row = l & 31, k = 16 s + 8 (l >> 5) ..) sits at
+//     ((l >> 4) & 1) * NKB KiB  +  (s >> 1) KiB  +  (s & 1) * 512  +  (l >> 5) * 256  +  (l & 15) * 16
+// of the super-block image: 16 consecutive 16-B slots per ds_read_b128 lane group, conflict-free.
+// Accumulator layout (32x32): lane holds query l & 31 and corpus rows (r & 3) + 8 (r >> 2) + 4 (l >> 5), r = 0..15.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kWideQ = 256;  // queries per pass of the 32-queries-per-wave kernels
+
+template <bool BF>
+__device__ __forceinline__ f32x16 mfma32(half8 a, half8 b, f32x16 c) {
+    if (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <int NKB, int MODE, bool BF>
+__global__ void __launch_bounds__(512, 2)
+mips_screen32_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, const char* __restrict__ Qhi, const float* __restrict__ qbound, int nq,
+                     int q_base, unsigned* __restrict__ gmax /* [nq] ordered(max s_hi); MODE 2: [G][kWideQ] */,
+                     u64* __restrict__ cand /* [waves][kWaveCandCap] */, int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int SB_BYTES = 2 * NKB * kFragBytes;
+    constexpr int CPW = NKB / 4;
+    constexpr int NS = 2 * NKB;  // 16-deep K slices
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = gridDim.x, b = blockIdx.x;
+    int n_it = (n_sb - b + G - 1) / G;  // >= 1 (grid <= n_sb)
+    if (MODE == 0 && n_it > kSampleStages) n_it = kSampleStages;
+    int step_ = 1;
+    if (MODE == 2 && n_it > kSampleStagesK) { step_ = n_it / kSampleStagesK; n_it = kSampleStagesK; }
+    const int sG = (MODE == 2 ? step_ : 1) * G;
+
+    issue_super_block<NKB>(Xhi, b, lds, wave, lane);
+    if (n_it > 1) issue_super_block<NKB>(Xhi, b + sG, lds + SB_BYTES, wave, lane);
+
+    const bool wave_active = wave * 32 < nq;
+    const int l31 = lane & 31, lh = lane >> 5;
+    half8 qf[NS];
+    {
+        // query row 32 w + l31 of the fragment-tiled query matrix (16-row blocks): K-slice s -> 16-B chunk 2 s + lh
+        const size_t qrow = (size_t)wave * 32 + l31;
+        const char* qp = Qhi + (qrow >> 4) * ((size_t)NKB * kFragBytes) + (qrow & 15) * 16 + lh * 256;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) qf[sl] = *(const half8*)(qp + (sl >> 1) * kFragBytes + (sl & 1) * 512);
+    }
+    const int qlocal = wave * 32 + l31;
+    const bool q_valid = qlocal < nq;
+    float band2 = 0.f;
+    float known = -FLT_MAX;
+    if (MODE == 1 && q_valid) {
+        band2 = 2.f * qbound[qlocal];
+        unsigned g = gmax[qlocal];
+        if (g) known = unord32(g);
+    }
+    // retire every load above before the loop (see mips_screen_kernel)
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) asm volatile("" : "+v"(qf[sl]));
+    asm volatile("" : "+v"(band2), "+v"(known));
+    float hmax = -FLT_MAX;
+    int my_cnt = 0;  // wave-uniform
+    u64* my_list = cand + ((size_t)b * 8 + wave) * kWaveCandCap;
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int rd_off = ((lane >> 4) & 1) * (NKB * kFragBytes) + lh * 256 + (lane & 15) * 16;
+
+    for (int it = 0; it < n_it; ++it) {
+        if (it + 1 < n_it)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (MODE == 1 && ((it + b) & 63) == 63 && wave_active) {  // exchange maxima with the other workgroups (see mips_screen_kernel)
+            float hm = fmaxf(hmax, __shfl_xor(hmax, 32));
+            float kn = known;
+            if (lane < 32 && q_valid) {
+                if (hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
+                unsigned g = load_u32_l2(gmax + qlocal);
+                if (g) kn = fmaxf(kn, unord32(g));
+            }
+            known = __shfl(kn, l31);
+        }
+        if (it + 2 < n_it) issue_super_block<NKB>(Xhi, b + (it + 2) * sG, lds + ((it + 2) % 3) * SB_BYTES, wave, lane);
+        if (!wave_active) continue;
+
+        const char* p = lds + (it % 3) * SB_BYTES + rd_off;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        constexpr int PF = 3;  // LDS reads run PF slices ahead of the MFMAs that consume them (issue order pinned below)
+        half8 xa[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) xa[i] = *(const half8*)(p + (i >> 1) * kFragBytes + (i & 1) * 512);
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const half8 cur = xa[sl % PF];
+            if (sl + PF < NS) xa[sl % PF] = *(const half8*)(p + ((sl + PF) >> 1) * kFragBytes + ((sl + PF) & 1) * 512);
+            acc = mfma32<BF>(cur, qf[sl], acc);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            if (sl + PF < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        const unsigned row0 = (unsigned)(b + it * sG) * 32u + 4u * (unsigned)lh;
+        const float cut = known - band2;
+        // Fast path: a super-block that lies completely inside the corpus and holds no score above the cut (almost all of
+        // them) costs 15 max operations and ONE ballot instead of 16 compare / ballot / branch sequences.
+        const bool whole = (long long)(b + it * sG) * 32 + 32 <= n_rows;  // wave-uniform
+        float m16 = acc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m16 = fmaxf(m16, acc[r]);
+        if (whole && (MODE != 1 || __ballot(q_valid && m16 >= cut) == 0ull)) {
+            if (q_valid) hmax = fmaxf(hmax, m16);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sc = acc[r];
+                const unsigned row = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
+                const bool ok = (long long)row < n_rows && q_valid;
+                if (ok) hmax = fmaxf(hmax, sc);
+                if (MODE == 1) {
+                    const bool hit = ok && sc >= cut;
+                    const u64 m = __ballot(hit);
+                    if (m) {  // wave-uniform
+                        const int slot = my_cnt + __popcll(m & lt);
+                        if (hit && slot < kWaveCandCap) my_list[slot] = ((u64)(unsigned)(q_base + qlocal) << 32) | row;
+                        my_cnt += __popcll(m);
+                    }
+                }
+            }
+        }
+        if (MODE == 1) known = fmaxf(known, fmaxf(hmax, __shfl_xor(hmax, 32)));  // the two lanes of a query share their maxima
+    }
+    if (MODE == 0) {
+        const float hm = fmaxf(hmax, __shfl_xor(hmax, 32));
+        if (lane < 32 && q_valid && hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
+    } else if (MODE == 2) {
+        const float hm = fmaxf(hmax, __shfl_xor(hmax, 32));
+        if (lane < 32 && q_valid) gmax[(size_t)b * kWideQ + qlocal] = hm > -FLT_MAX ? ord32(hm) : 0u;
     } else if (lane == 0) {
         cand_cnt[b * 8 + wave] = my_cnt < kWaveCandCap ? my_cnt : kWaveCandCap;
         if (my_cnt > kWaveCandCap) *overflow = 1;
@@ -1259,6 +1419,11 @@ int add_any(mdr_index* h, const void* src_dev, int dtype, long long n, long long
 size_t elem_size(int dtype) { return dtype == MDR_DT_F32 ? 4 : 2; }
 
 bool is_bf16(const mdr_index* h) { return h->storage == MDR_STORE_BF16; }
+// MDR_MIPS_WIDE=0 keeps every call on the 128-queries-per-pass kernels (measurement knob)
+bool wide_pass(int nq) {
+    static const bool off = getenv("MDR_MIPS_WIDE") && atoi(getenv("MDR_MIPS_WIDE")) == 0;
+    return !off && nq > kStreamQ;
+}
 bool stream_kernel_supports(const mdr_index* h, int k) { return !is_bf16(h) && h->d == 768 && k <= 128; }
 bool screen_kernel_supports(const mdr_index* h, int k) { return h->d == 768 && k <= 128; }
 
@@ -1293,7 +1458,7 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     p.lists_generic = p.path == PATH_GENERIC || (p.path == PATH_SCREEN && is_bf16(h));
     const bool screenk = p.path == PATH_SCREEN && k > 1;
     const bool frag = p.path != PATH_GENERIC;
-    const size_t nq_pad = (size_t)((nq + kStreamQ - 1) / kStreamQ) * kStreamQ;
+    const size_t nq_pad = (size_t)((nq + kWideQ - 1) / kWideQ) * kWideQ;  // covers both group sizes (128 and 256 queries per pass)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
     p.off_qhi = take(frag ? nq_pad * h->d * 2 : 0);
@@ -1303,7 +1468,7 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     p.off_best = take((size_t)(nq > 0 ? nq : 1) * 8);
     p.off_gmax = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
     // k == 1: one private list per wave; k > 1: the [G][kStreamQ] sample maxima
-    p.off_scand = take(p.path != PATH_SCREEN ? 0 : (k == 1 ? (size_t)p.G * 8 * kWaveCandCap * 8 : (size_t)p.G * kStreamQ * 4));
+    p.off_scand = take(p.path != PATH_SCREEN ? 0 : (k == 1 ? (size_t)p.G * 8 * kWaveCandCap * 8 : (size_t)p.G * kWideQ * 4));
     p.off_sctl = take(p.path == PATH_SCREEN ? 256 + (size_t)p.G * 8 * 4 : 0);            // [0] overflow flag, [64..] per-wave counts
     // the screen-k lists and the lists of its conditional exact pass (which runs after them in stream order) share one region
     size_t lists = p.lists_stream ? (size_t)p.Gx * kStreamQ * kStreamCap : (p.lists_generic ? (size_t)p.Gg * kGenericQ * kGenericCap : 0);
@@ -1366,6 +1531,39 @@ int run_screen(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, 
                            (const float*)(bound + (size_t)gi * kStreamQ), nqg, gi * kStreamQ, gmax + (size_t)gi * kStreamQ, scand, wave_cnt, sctl);
         hipLaunchKernelGGL((mips_screen_kernel<NKB, 1, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
                            (const float*)(bound + (size_t)gi * kStreamQ), nqg, gi * kStreamQ, gmax + (size_t)gi * kStreamQ, scand, wave_cnt, sctl);
+        hipLaunchKernelGGL((mips_refine_kernel<BF>), dim3(p.G * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
+                           (const u64*)scand, (const int*)wave_cnt, best);
+        MDR_HIP_TRY(hipGetLastError());
+    }
+    return MDR_OK;
+}
+
+// k == 1, more than 128 queries: the same three launches per group of 256 queries on the 32-queries-per-wave kernel
+template <bool BF>
+int run_screen32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, const char* qhi, u64* best, hipStream_t st) {
+    constexpr int NKB = 24;
+    const size_t lds_bytes = 3 * (size_t)NKB * 2 * kFragBytes;
+    int rc_ = ensure_dynamic_lds((const void*)mips_screen32_kernel<NKB, 0, BF>, (int)lds_bytes);
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen32_kernel<NKB, 1, BF>, (int)lds_bytes);
+    if (rc_) return rc_;
+    float* bound = (float*)(ws + p.off_bound);
+    unsigned* gmax = (unsigned*)(ws + p.off_gmax);
+    u64* scand = (u64*)(ws + p.off_scand);
+    int* sctl = (int*)(ws + p.off_sctl);
+    int* wave_cnt = sctl + 64;
+    const int ngroups = (nq + kWideQ - 1) / kWideQ;
+    const int nq_pad = ngroups * kWideQ;
+    const int n_sb = (int)((h->ntotal + 31) / 32);
+    const size_t qgroup_bytes = (size_t)kWideQ * h->d * 2;
+    MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
+    MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int nqg = nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ;
+        const char* qg = qhi + gi * qgroup_bytes;
+        hipLaunchKernelGGL((mips_screen32_kernel<NKB, 0, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
+                           (const float*)(bound + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, sctl);
+        hipLaunchKernelGGL((mips_screen32_kernel<NKB, 1, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
+                           (const float*)(bound + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, sctl);
         hipLaunchKernelGGL((mips_refine_kernel<BF>), dim3(p.G * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
                            (const u64*)scand, (const int*)wave_cnt, best);
         MDR_HIP_TRY(hipGetLastError());
@@ -1526,9 +1724,11 @@ int mdr_index_set_variant(mdr_index* h, int variant) {
 
 const char* mdr_index_last_kernel(const mdr_index* h) { return h ? h->last_kernel : "none"; }
 
-int mdr_index_queries_per_pass(const mdr_index* h, int k) {
-    if (!h || k < 1 || k > kKMax) return 0;
-    return make_plan(h, 1, k).path == PATH_GENERIC ? kGenericQ : kStreamQ;
+int mdr_index_queries_per_pass(const mdr_index* h, int nq, int k) {
+    if (!h || k < 1 || k > kKMax || nq < 1) return 0;
+    const int path = make_plan(h, nq, k).path;
+    if (path == PATH_GENERIC) return kGenericQ;
+    return path == PATH_SCREEN && k == 1 && wide_pass(nq) ? kWideQ : kStreamQ;
 }
 
 size_t mdr_index_search_workspace_bytes(const mdr_index* h, int nq, int k) {
@@ -1583,7 +1783,7 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
         // |q.x - qh.xh| <= c |q| max|x|: fp16 rounding of both operands (2^-10) or bf16 rounding of q only (2^-9; the
         // stored rows ARE the bf16 values), plus fp32 accumulation slack
         const float c = bf ? 2.2e-3f : 1.2e-3f;
-        const int nq_pad = ngroups * kStreamQ;
+        const int nq_pad = (nq + kWideQ - 1) / kWideQ * kWideQ;
         float* bound = (float*)(ws + p.off_bound);
         MDR_HIP_TRY(hipMemsetAsync(h->flags + 1, 0, sizeof(int), st));  // "a query of THIS call was non-finite" (telemetry)
         if (bf)
@@ -1597,10 +1797,15 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
         MDR_HIP_TRY(hipMemsetAsync(best, 0, (size_t)nq * 8, st));
         const int* run_if = nullptr;
         if (p.path == PATH_SCREEN) {
-            rc = bf ? run_screen<true>(h, p, ws, q_dev, nq, qhi, best, st) : run_screen<false>(h, p, ws, q_dev, nq, qhi, best, st);
+            if (wide_pass(nq)) {  // more than 128 queries: 256 per corpus pass on the 32-queries-per-wave kernel
+                rc = bf ? run_screen32<true>(h, p, ws, q_dev, nq, qhi, best, st) : run_screen32<false>(h, p, ws, q_dev, nq, qhi, best, st);
+                h->last_kernel = bf ? "mips_screen32_kernel<24,1,bf16>" : "mips_screen32_kernel<24,1>";
+            } else {
+                rc = bf ? run_screen<true>(h, p, ws, q_dev, nq, qhi, best, st) : run_screen<false>(h, p, ws, q_dev, nq, qhi, best, st);
+                h->last_kernel = bf ? "mips_screen_kernel<24,1,bf16>" : "mips_screen_kernel<24,1>";
+            }
             if (rc) return rc;
             run_if = (const int*)(ws + p.off_sctl);  // exact pass below: only if a candidate list overflowed
-            h->last_kernel = bf ? "mips_screen_kernel<24,1,bf16>" : "mips_screen_kernel<24,1>";
         } else {
             h->last_kernel = "mips_stream_kernel<24,0>";
         }

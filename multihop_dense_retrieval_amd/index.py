@@ -108,9 +108,9 @@ class IndexFlatIP:
         """HBM bytes one search call reads for the corpus (algorithmic bytes of the roofline)."""
         return int(_lib.lib().mdr_index_stream_bytes(self._h))
 
-    def queries_per_pass(self, k=1):
-        """Queries one pass over the shard serves (a search with nq queries reads the corpus ceil(nq / this) times)."""
-        return int(_lib.lib().mdr_index_queries_per_pass(self._h, int(k)))
+    def queries_per_pass(self, nq, k=1):
+        """Queries one pass over the shard serves for a call of nq queries (the corpus is read ceil(nq / this) times)."""
+        return int(_lib.lib().mdr_index_queries_per_pass(self._h, int(nq), int(k)))
 
     def telemetry(self, nq, k):
         """Test hook (synchronises): {"fallback", "candidates", "bad_query", "path"} of the last search of this shape."""
