@@ -77,6 +77,10 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true", help="debug: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--pmc-traffic", type=float, default=None, help="HBM bytes per launch from a rocprofv3 --pmc pass")
     ap.add_argument("--no-verify", action="store_true", help="skip the full-size brute-force exactness check after the timed region")
+    ap.add_argument("--sequential", action="store_true",
+                    help="one batch at a time (hop-1 encode, search, hop-2 encode, search as four dependent stages). Default: the "
+                         "software-pipelined loop -- hop 2 of batch i and hop 1 of batch i+1 share one encoder forward and one corpus pass")
+    ap.add_argument("--no-sequential", action="store_true", help="pipelined run: do not append the sequential sub-result")
     ap.add_argument("--dump-ids", default=None, help="rank 0 writes the last step's hop-1 / hop-2 ids and scores to this .npz (tests)")
     ap.add_argument("--no-strong", action="store_true", help="N>1, weak scaling: do not append the strong-scaling sub-result")
     return ap.parse_args()
@@ -253,7 +257,8 @@ def main():
 
     pipe = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device,
                                 max_q_len=args.max_q_len, max_q_sp_len=args.max_q_sp_len,
-                                use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank, world=world, weak=weak)
+                                use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank, world=world, weak=weak,
+                                pipelined=not args.sequential)
     out, elapsed = timed_steps(pipe, args, world, device, dist)
 
     # self-checks, outside the timed region: structural properties + exactness against a brute-force pass over ALL rows
@@ -314,7 +319,10 @@ def main():
                                f"{B}-question batches{' per GPU (global batch ' + str(GB) + ')' if weak else ''}, 2-hop beam={args.beam} topk={args.topk}"
                                f"{' , MIPS-only (no encoder)' if not pipe.use_encoder else ', RoBERTa-base encoder (random init)'}",
                    "rows": N, "dim": d, "batch": B, "global_batch": GB, "beam": args.beam, "topk": args.topk, "shards": world,
-                   "encoder": pipe.encoder_desc(), "index_build_s": round(build_s, 2)},
+                   "encoder": pipe.encoder_desc(), "index_build_s": round(build_s, 2),
+                   "loop": ("software-pipelined: hop 2 of batch i and hop 1 of batch i+1 share one encoder forward and one corpus pass "
+                            "(every batch still walks the full hop-1 -> hop-2 chain; see `sequential` for the unpipelined loop)") if pipe.pipelined
+                           else "sequential: one batch at a time, four dependent stages"},
         "roofline": roofline,
         "self_check": ok,
         "stage_ms": stage,
@@ -325,7 +333,7 @@ def main():
         sp_lens = out["mask2"].sum(1).cpu().numpy()
         e1, p1 = encoder_flops(q_lens, args.max_q_len)
         e2, p2 = encoder_flops(sp_lens, args.max_q_sp_len)
-        enc_ms = stage["hop1_encode"] + stage["hop2_encode"]
+        enc_ms = stage["hop1_encode"] + stage["hop2_encode"]  # pipelined: ONE forward carries both (hop1_encode is 0)
         if world > 1 and not weak:  # strong scaling: each rank encodes 1/world of the rows, the rest of the stage is the all-gather
             e1, p1, e2, p2 = e1 / world, p1 / world, e2 / world, p2 / world
         ach = (e1 + e2) / (enc_ms * 1e-3) / 1e12
@@ -334,20 +342,40 @@ def main():
             "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
             "executed_flop_per_step": round(e1 + e2), "padded_equivalent_flop_per_step": round(p1 + p2),
             "padded_equivalent_TFLOPs": round((p1 + p2) / (enc_ms * 1e-3) / 1e12, 1),
-            "hop1": {"ms": stage["hop1_encode"], "tokens": int(q_lens.sum()), "TFLOPs": round(e1 / (stage["hop1_encode"] * 1e-3) / 1e12, 1)},
-            "hop2": {"ms": stage["hop2_encode"], "tokens": int(sp_lens.sum()), "TFLOPs": round(e2 / (stage["hop2_encode"] * 1e-3) / 1e12, 1)},
+            "hop1": {"ms": stage["hop1_encode"], "tokens": int(q_lens.sum()),
+                     "TFLOPs": round(e1 / (stage["hop1_encode"] * 1e-3) / 1e12, 1) if stage["hop1_encode"] > 0 else None},
+            "hop2": {"ms": stage["hop2_encode"], "tokens": int(sp_lens.sum()) + (int(q_lens.sum()) if pipe.pipelined else 0),
+                     "TFLOPs": round((e2 + (e1 if pipe.pipelined else 0)) / (stage["hop2_encode"] * 1e-3) / 1e12, 1)},
             "share_of_step": round(enc_ms / ms_per_step, 3),
             "note": "executed FLOPs (masked tokens dropped, last layer CLS-only) / HIP-event stage time on the launch stream; peak = dense fp16 MFMA"}
     result["stage_share"] = {"encoder": round((stage.get("hop1_encode", 0) + stage.get("hop2_encode", 0)) / ms_per_step, 3),
                              "mips": round((stage.get("hop1_search", 0) + stage.get("hop2_search", 0)) / ms_per_step, 3)}
 
+    if pipe.pipelined and not args.no_sequential:
+        # the same job, one batch at a time (the loop exactly as the reference writes it): sub-result of the same line
+        mhop.SyntheticTwoHop._defer_encoder = True  # share the encoder and the arena of the main pipeline
+        pipe_q = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
+                                      max_q_sp_len=args.max_q_sp_len, use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank,
+                                      world=world, weak=weak, pipelined=False)
+        mhop.SyntheticTwoHop._defer_encoder = False
+        if pipe.use_encoder:
+            pipe_q.encoder, pipe_q.arena = pipe.encoder, pipe.arena  # same weights, same token arena
+        _, el_q = timed_steps(pipe_q, args, world, device, dist)
+        result["sequential"] = {"value": round(GB * args.steps / el_q, 2), "unit": "queries/s", "ms_per_step": round(el_q / args.steps * 1e3, 4),
+                                "stage_ms": pipe_q.stage_ms()}
+        del pipe_q
+
     if world > 1 and weak and not args.no_strong:
         # The same job with ONE 100-question batch shared by all ranks (the reference's fixed --batch-size): a sub-result of
         # the same JSON line, so a scaling run carries the strong-scaling number next to the weak one.
-        del pipe, out
+        mhop.SyntheticTwoHop._defer_encoder = True
         pipe_s = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
                                       max_q_sp_len=args.max_q_sp_len, use_encoder=not args.no_encoder,
-                                      planted_rows=torch.zeros((B, d), device=device), rank=rank, world=world, weak=False)
+                                      planted_rows=torch.zeros((B, d), device=device), rank=rank, world=world, weak=False,
+                                      pipelined=pipe.pipelined)
+        mhop.SyntheticTwoHop._defer_encoder = False
+        if pipe.use_encoder:
+            pipe_s.encoder, pipe_s.arena = pipe.encoder, pipe.arena
         _, el_s = timed_steps(pipe_s, args, world, device, dist)
         result["strong_scaling"] = {"value": round(B * args.steps / el_s, 2), "unit": "queries/s", "ms_per_step": round(el_s / args.steps * 1e3, 4),
                                     "global_batch": B, "note": "one batch of --batch questions for all ranks: encoder slices split over ranks + all-gather"}

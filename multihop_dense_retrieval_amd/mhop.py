@@ -132,7 +132,7 @@ class SyntheticTwoHop:
     VOCAB = 50265
 
     def __init__(self, index, batch, beam, topk, dim, device, max_q_len=70, max_q_sp_len=350, use_encoder=True,
-                 planted_rows=None, rank=0, world=1, weak=False):
+                 planted_rows=None, rank=0, world=1, weak=False, pipelined=False):
         """`weak=False`: ONE batch of `batch` questions shared by all ranks (strong scaling: the encoder work is split).
         `weak=True`: every rank owns its own batch of `batch` questions (global batch = batch * world): it encodes them,
         the embeddings of all ranks are all-gathered, every rank searches ALL of them in its row shard, the per-shard
@@ -140,6 +140,9 @@ class SyntheticTwoHop:
         self.index, self.B, self.beam, self.topk, self.d, self.device = index, batch, beam, topk, dim, device
         self.Lq, self.Lsp = max_q_len, max_q_sp_len
         self.use_encoder = use_encoder
+        self.pipelined = bool(pipelined)
+        self._carry = None  # pipelined mode: (q, D, I) of the batch whose hop 1 is already done
+        self._side = None   # side stream of the pipelined loop
         self.rank, self.world = rank, world
         self.weak = bool(weak) and world > 1
         self.local = getattr(index, "local", index)
@@ -157,7 +160,7 @@ class SyntheticTwoHop:
         self.planted_rows = planted_rows
         self.encoder = None
         self.arena = None
-        if use_encoder:
+        if use_encoder and not getattr(SyntheticTwoHop, "_defer_encoder", False):
             from .arena import TokenArena
             from .retriever import RobertaRetriever
             self.encoder = RobertaRetriever.random_init(device=device, seed=3)
@@ -175,10 +178,17 @@ class SyntheticTwoHop:
         n = t.shape[0] // self.world
         return t[self.rank * n:(self.rank + 1) * n]
 
-    def _encode(self, ids, mask):
+    def _interleave(self, a, b):
+        """Weak scaling: both tensors are all-gathered per rank ([world * na], [world * nb]); the fused search wants each
+        rank's rows together: [rank][na + nb]."""
+        w = self.world
+        na, nb = a.shape[0] // w, b.shape[0] // w
+        return torch.cat([a.view(w, na, -1), b.view(w, nb, -1)], 1).reshape(w * (na + nb), -1)
+
+    def _encode(self, ids, mask, lane=0):
         if self.weak:
             from .index import all_gather_dim0
-            return all_gather_dim0(self.encoder.encode_q(ids, mask, None), self.world)
+            return all_gather_dim0(self.encoder.encode_q(ids, mask, None, lane=lane), self.world)
         if self.world > 1:
             # data-parallel encoder: each rank encodes a contiguous slice, embeddings are all-gathered
             n = ids.shape[0]
@@ -186,10 +196,10 @@ class SyntheticTwoHop:
             lo, hi = min(n, self.rank * per), min(n, (self.rank + 1) * per)
             part = torch.zeros((per, self.d), device=self.device)
             if hi > lo:
-                part[: hi - lo] = self.encoder.encode_q(ids[lo:hi], mask[lo:hi], None)
+                part[: hi - lo] = self.encoder.encode_q(ids[lo:hi], mask[lo:hi], None, lane=lane)
             from .index import all_gather_dim0
             return all_gather_dim0(part, self.world)[:n].contiguous()
-        return self.encoder.encode_q(ids, mask, None)
+        return self.encoder.encode_q(ids, mask, None, lane=lane)
 
     # -- one step ----------------------------------------------------------------------------------------
     def _mark(self):
@@ -206,7 +216,79 @@ class SyntheticTwoHop:
             return D, I
         return self.index.search_gathered(D, I)
 
+    # -- software-pipelined step ------------------------------------------------------------------------------
+    def _hop1_only(self):
+        """Prologue of the pipelined loop: hop 1 of the first batch."""
+        if self.use_encoder:
+            q = self._encode(self.q_ids, self.q_mask)
+        else:
+            q = self.planted_rows + self.noise
+            if self.weak:
+                from .index import all_gather_dim0
+                q = all_gather_dim0(q, self.world)
+        D, I = self._search(q, self.beam)
+        if self.weak:
+            q, D, I = self._own(q), self._own(D).contiguous(), self._own(I).contiguous()
+        return q, D, I
+
+    def _step_pipelined(self):
+        """Batches are independent, so hop 2 of batch i and hop 1 of batch i+1 share ONE encoder forward (the packed,
+        un-padded execution takes 350- and 70-token rows in one call) and ONE corpus pass (B*beam + B queries; more than
+        128 queries go 256 per pass). Every question still walks hop-1 encode -> search -> hop-2 assembly -> hop-2 encode
+        -> search -> path ranking with the same arithmetic; what changes is that the small, latency-bound hop-1 work rides
+        along with the previous batch's large hop-2 work instead of paying its own ~140 launches and its own corpus pass.
+        In the steady state one call finishes one batch and starts the next, i.e. per step exactly one hop-1 and one hop-2
+        of every kind of work, as in the sequential step."""
+        if self._carry is None:
+            self._carry = self._hop1_only()
+            self._search_ev = self._search_ev[:-1] if self._search_ev else self._search_ev  # the prologue is not a timed call
+        q, D, I = self._carry
+        B, bm = self.B, self.beam
+        ev = [self._mark()]
+        ev.append(ev[0])  # (no separate hop-1 stages)
+        ev.append(ev[0])
+        if self.use_encoder:
+            # the next batch's questions on a side stream / second encoder lane, beside this batch's hop-2 forward: ~140 short,
+            # latency-bound launches that fill the gaps of the large forward instead of running alone
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            start = torch.cuda.Event()
+            start.record()
+            self._side.wait_event(start)
+            with torch.cuda.stream(self._side):
+                q_next = self._encode(self.q_ids, self.q_mask, lane=1)
+                done = torch.cuda.Event()
+                done.record()
+            ids, mask = self._hop2_inputs(I, D)  # hop-2 inputs of batch i
+            ev.append(self._mark())
+            q2 = self._encode(ids, mask)
+            torch.cuda.current_stream().wait_event(done)
+            q_next.record_stream(torch.cuda.current_stream())
+            e = torch.cat([q2, q_next], 0) if not self.weak else self._interleave(q2, q_next)
+        else:
+            ids = mask = None
+            ev.append(self._mark())
+            q2 = (0.5 * q).repeat_interleave(bm, 0) + self.table[(I.reshape(-1) % 1024)]
+            e = torch.cat([q2, self.planted_rows + self.noise], 0).contiguous()
+            if self.weak:
+                from .index import all_gather_dim0
+                e = all_gather_dim0(e, self.world)
+        ev.append(self._mark())
+        Dc, Ic = self._search(e.contiguous(), bm)
+        if self.weak:
+            e, Dc, Ic = self._own(e), self._own(Dc), self._own(Ic)
+        q2, q_next = e[:B * bm], e[B * bm:]
+        D2, I2 = Dc[:B * bm].contiguous(), Ic[:B * bm].contiguous()
+        self._carry = (q_next, Dc[B * bm:].contiguous(), Ic[B * bm:].contiguous())
+        ev.append(self._mark())
+        h1, h2, sc = rank_paths_device(D, I, D2, I2, bm, self.topk)
+        ev.append(self._mark())
+        self._ev.append(ev)
+        return {"q": q, "q2": q2, "D": D, "I": I, "D2": D2, "I2": I2, "hop1": h1, "hop2": h2, "score": sc, "ids2": ids, "mask2": mask}
+
     def step(self):
+        if self.pipelined:
+            return self._step_pipelined()
         ev = [self._mark()]
         if self.use_encoder:
             q = self._encode(self.q_ids, self.q_mask)

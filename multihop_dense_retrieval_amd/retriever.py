@@ -68,6 +68,13 @@ def expected_state_dict_shapes(config, with_pooler=True):
     return sd
 
 
+class _Lane:
+    def __init__(self):
+        self.ws = None
+        self.graphs = OrderedDict()  # (B, L bucket) -> capture, LRU order
+        self.seen = {}
+
+
 class _HipRobertaEncoder:
     """Shared implementation of the two reference classes (they compute the same function,
     SURVEY.md §8a row a23)."""
@@ -80,9 +87,9 @@ class _HipRobertaEncoder:
         self.args = args
         self._shapes = expected_state_dict_shapes(config)
         self._h = ctypes.c_void_p()
-        self._ws = None
-        self._graphs = OrderedDict()  # (B, L bucket) -> capture, LRU order
-        self._seen = {}
+        # per-lane scratch state: a lane = one workspace + its captured graphs. Two forwards may be in flight at once (on two
+        # streams) when they use different lanes; the C handle itself only holds the weights.
+        self._lanes = {}
         self.capture_on_first_use = False
         self.graph_captures = 0
         self.graph_replays = 0
@@ -134,7 +141,15 @@ class _HipRobertaEncoder:
     GRAPH_L_BUCKET = 32       # graph keys use seq_len rounded up to this (padding columns are free: execution is un-padded)
     GRAPH_CACHE_ENTRIES = 24  # LRU bound on captured shapes
 
-    def encode_seq(self, input_ids, mask):
+    def _lane(self, lane):
+        st = self._lanes.get(lane)
+        if st is None:
+            st = self._lanes[lane] = _Lane()
+        return st
+
+    def encode_seq(self, input_ids, mask, lane=0):
+        """lane: which workspace / graph cache this call uses. Calls on DIFFERENT lanes may overlap on different streams (the
+        pipelined retrieval loop encodes the next batch's questions beside the current batch's hop-2 inputs)."""
         if not self._h.value:
             raise RuntimeError("encoder has no weights on a device: call load_saved(...)/load_state_dict(...) and .to('cuda') first")
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
@@ -143,27 +158,28 @@ class _HipRobertaEncoder:
             raise ValueError(f"input_ids {tuple(ids.shape)} and mask {tuple(msk.shape)} must both be [B, L]")
         B, L = ids.shape
         if self.use_graphs and 0 < B * L <= self.MAX_TOKENS_PER_CALL and L <= 512:
-            return self._encode_graphed(ids, msk)
+            return self._encode_graphed(ids, msk, lane)
         out = torch.empty((B, self.config.hidden_size), dtype=torch.float32, device=self.device)
-        self._forward_into(ids, msk, out)
+        self._forward_into(ids, msk, out, lane)
         return out
 
-    def _forward_into(self, ids, msk, out):
+    def _forward_into(self, ids, msk, out, lane=0):
+        st = self._lane(lane)
         B, L = ids.shape
         per = max(1, self.MAX_TOKENS_PER_CALL // L)
         L_ = _lib.lib()
         for lo in range(0, B, per):
             hi = min(B, lo + per)
             need = int(L_.mdr_encoder_workspace_bytes(self._h, hi - lo, L))
-            if self._ws is None or self._ws.numel() < need:
+            if st.ws is None or st.ws.numel() < need:
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("encoder workspace must be sized before graph capture")
-                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                st.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             _lib.check(L_.mdr_encoder_forward(self._h, ctypes.c_void_p(ids[lo:hi].data_ptr()), ctypes.c_void_p(msk[lo:hi].data_ptr()), hi - lo, L,
-                                              ctypes.c_void_p(out[lo:hi].data_ptr()), ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(),
+                                              ctypes.c_void_p(out[lo:hi].data_ptr()), ctypes.c_void_p(st.ws.data_ptr()), st.ws.numel(),
                                               _lib.current_stream_ptr(self.device)))
 
-    def _encode_graphed(self, ids, msk):
+    def _encode_graphed(self, ids, msk, lane=0):
         """One forward is ~140 short kernel launches; for the small batches of the retrieval loop (and for each
         rank's slice under multi-GPU data parallelism) the launch gaps dominate. The launch sequence depends only
         on (B, L), so it is captured into a hipGraph and replayed (static input/output buffers).
@@ -175,17 +191,18 @@ class _HipRobertaEncoder:
         is dropped as a whole when the workspace is re-allocated (captures hold raw pointers into it)."""
         B, L = ids.shape
         Lb = min(512, -(-L // self.GRAPH_L_BUCKET) * self.GRAPH_L_BUCKET)
+        st = self._lane(lane)
         key = (B, Lb)
-        ent = self._graphs.get(key)
-        if ent is not None and ent[4] is not self._ws:  # stale: the workspace moved since the capture
-            self._graphs.clear()
+        ent = st.graphs.get(key)
+        if ent is not None and ent[4] is not st.ws:  # stale: the workspace moved since the capture
+            st.graphs.clear()
             ent = None
         if ent is None:
-            seen = self._seen.get(key, 0) + 1
-            self._seen[key] = seen
+            seen = st.seen.get(key, 0) + 1
+            st.seen[key] = seen
             if seen < 2 and not self.capture_on_first_use:
                 out = torch.empty((B, self.config.hidden_size), dtype=torch.float32, device=self.device)
-                self._forward_into(ids, msk, out)
+                self._forward_into(ids, msk, out, lane)
                 return out
             sid = torch.full((B, Lb), int(self.config.pad_token_id), dtype=torch.int64, device=self.device)
             smk = torch.zeros((B, Lb), dtype=torch.int64, device=self.device)
@@ -197,20 +214,20 @@ class _HipRobertaEncoder:
             fill = float(smk.sum().item()) / float(smk.numel()) if os.environ.get("MDR_FILL_HINT", "1") != "0" else 0.0
             _lib.check(_lib.lib().mdr_encoder_set_fill_hint(self._h, min(1.0, max(fill, 1e-3)) if fill > 0 else 0.0))
             try:
-                self._forward_into(sid, smk, sout)  # warm-up: sizes the workspace, sets kernel attributes
+                self._forward_into(sid, smk, sout, lane)  # warm-up: sizes the workspace, sets kernel attributes
                 torch.cuda.synchronize(self.device)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    self._forward_into(sid, smk, sout)
+                    self._forward_into(sid, smk, sout, lane)
             finally:
                 _lib.check(_lib.lib().mdr_encoder_set_fill_hint(self._h, 0.0))
-            ent = (graph, sid, smk, sout, self._ws)
-            while len(self._graphs) >= self.GRAPH_CACHE_ENTRIES:
-                self._graphs.popitem(last=False)  # least recently used
-            self._graphs[key] = ent
+            ent = (graph, sid, smk, sout, st.ws)
+            while len(st.graphs) >= self.GRAPH_CACHE_ENTRIES:
+                st.graphs.popitem(last=False)  # least recently used
+            st.graphs[key] = ent
             self.graph_captures += 1
             return sout.clone()  # the warm-up / capture pair already produced this batch's result
-        self._graphs.move_to_end(key)
+        st.graphs.move_to_end(key)
         graph, sid, smk, sout, _ = ent
         sid[:, :L].copy_(ids)
         smk[:, :L].copy_(msk)
@@ -274,8 +291,8 @@ class _HipRobertaEncoder:
 class RobertaRetriever(_HipRobertaEncoder):
     """mhop_retriever.py:12-41 -- query encoder; `encode_q(ids, mask, type_ids)` ignores type_ids like the reference."""
 
-    def encode_q(self, input_ids, q_mask, q_type_ids=None):
-        return self.encode_seq(input_ids, q_mask)
+    def encode_q(self, input_ids, q_mask, q_type_ids=None, lane=0):
+        return self.encode_seq(input_ids, q_mask, lane)
 
     def __call__(self, batch):
         raise NotImplementedError("training forward (six encode_seq calls, mhop_retriever.py:28-38) is outside the retrieval hot path")
