@@ -47,8 +47,10 @@ CHUNK_ROWS = 250_000
 
 # measured HBM fetch bytes per search call / algorithmic bytes (N_pad * d * 4), from rocprofv3 --pmc FETCH_SIZE passes
 PMC_TRAFFIC_RATIO = {
-    # main 3.75166e6 KB + refine 28996 KB + sample 25367 KB, x2 -> 7.79e9 B at 5M x 768 (15.36e9 B algorithmic)
-    "mips_screen_kernel": (0.5072, "profiles/r01_final_mips5m_pmc_screen_FETCH_SIZE.csv"),
+    # 16 queries per wave: main 3.75164e6 KB + refine 29030 KB + sample 25376 KB, x2 -> 7.794e9 B per search at 5M x 768 (15.36e9 B algorithmic)
+    "mips_screen_kernel": (0.5074, "profiles/r02_mips5m_pmc_sequential_FETCH_SIZE.csv"),
+    # 32 queries per wave: main 3.75258e6 KB + refine 52561 KB + sample 26145 KB, x2 -> 7.847e9 B per search (200 queries)
+    "mips_screen32_kernel": (0.5109, "profiles/r02_mips5m_pmc_pipelined_FETCH_SIZE.csv"),
     "mips_stream_kernel": (1.001, "profiles/r01_mips1m_pmc_fetch_size.csv"),
 }
 

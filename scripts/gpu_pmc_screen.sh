@@ -1,22 +1,35 @@
 #!/bin/bash
-# HBM traffic (FETCH_SIZE) and SQ counters of the MIPS screen kernel at 5M rows -> gpurun_out/<tag>/
+# HBM traffic (FETCH_SIZE / WRITE_SIZE) and SQ counters of the MIPS screen kernels at 5M rows -> gpurun_out/<tag>/
+#   sequential loop: mips_screen_kernel   (16 queries per wave, nq = 100 per call)
+#   pipelined loop : mips_screen32_kernel (32 queries per wave, nq = 200 per call)
+# Counters are collected in their own passes with --kernel-trace only (no other trace domain).
 set -u
 TAG=${1:-pmcs}; REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 cd /tmp
-for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
-  N=$(echo $PMC | tr ' ' '_' | cut -c1-30)
-  timeout 300 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/p -o p -- python $REPO/bench.py --rows 5000000 --steps 3 --warmup 1 --no-encoder --no-cpu-baseline > $OUT/log_$N.txt 2>&1
-  P=$(find $OUT/p -name "*counter_collection.csv" | head -1)
-  if [ -n "$P" ]; then head -1 "$P" > $OUT/screen_$N.csv; grep -E "mips_(screen|refine)" "$P" >> $OUT/screen_$N.csv; fi
-  rm -rf $OUT/p
+for MODE in sequential pipelined; do
+  FLAG=""; [ $MODE = sequential ] && FLAG="--sequential"
+  for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
+    N=$(echo $PMC | tr ' ' '_' | cut -c1-30)
+    timeout 300 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/p -o p -- python $REPO/bench.py --rows 5000000 --steps 3 --warmup 1 --no-encoder --no-cpu-baseline --no-sequential --no-verify $FLAG > $OUT/log_${MODE}_$N.txt 2>&1
+    P=$(find $OUT/p -name "*counter_collection.csv" | head -1)
+    if [ -n "$P" ]; then head -1 "$P" > $OUT/${MODE}_$N.csv; grep -E "mips_(screen|screen32|refine)" "$P" >> $OUT/${MODE}_$N.csv; fi
+    rm -rf $OUT/p
+  done
 done
-python - $OUT <<'PY'
-import csv, glob, sys, collections
-for f in sorted(glob.glob(sys.argv[1] + "/screen_*.csv")):
+python - $OUT <<'PY' | tee $OUT/summary.txt
+import csv, glob, sys, collections, os
+for f in sorted(glob.glob(sys.argv[1] + "/*_*.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        k = ("main" if "<24, 1" in r["Kernel_Name"] else "sample" if "<24, 0" in r["Kernel_Name"] else "refine")
-        agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        n = r["Kernel_Name"]
+        kern = "screen32" if "screen32" in n else "screen" if "mips_screen_kernel" in n else "refine"
+        mode = "main" if "<24, 1" in n else "sample" if "<24, 0" in n else ""
+        dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        agg[(kern + " " + mode, r["Counter_Name"])].append((float(r["Counter_Value"]), dur))
     for (k, c), v in sorted(agg.items()):
-        print(f"{k:7s} {c:28s} mean {sum(v)/len(v):.6g} n={len(v)}")
+        mean = sum(x for x, _ in v) / len(v)
+        extra = ""
+        if c == "FETCH_SIZE":  # KB; gfx950: x2 (MI355X_MICROARCH.md, HBM)
+            extra = f"  -> {mean * 1024 * 2 / 1e9:.3f} GB per launch (x2 corrected), {mean * 1024 * 2 / (sum(d for _, d in v) / len(v)):.1f} GB/s at the profiled duration"
+        print(f"{os.path.basename(f):44s} {k:16s} {c:28s} mean {mean:.6g} n={len(v)} avg_ns={sum(d for _, d in v) / len(v):.0f}{extra}")
 PY
