@@ -899,13 +899,13 @@ __device__ inline u64 wave_select_band(u64* list, int c, int k, float band2, int
 }
 
 // k-th largest of the G per-workgroup sample maxima of each query -> tau0 (-inf when fewer than k workgroups saw a row)
-__global__ void __launch_bounds__(256) kth_of_maxima_kernel(const unsigned* __restrict__ wgmax /* [G][kStreamQ] ordered, 0 = none */, int G, int k,
-                                                            float* __restrict__ tau0 /* [kStreamQ] */) {
+__global__ void __launch_bounds__(256) kth_of_maxima_kernel(const unsigned* __restrict__ wgmax /* [G][qcap] ordered, 0 = none */, int G, int k,
+                                                            float* __restrict__ tau0 /* [qcap] */, int qcap) {
     const int ql = blockIdx.x;
     __shared__ unsigned v[1024];
     __shared__ int found;
     if (threadIdx.x == 0) found = 0;
-    for (int i = threadIdx.x; i < G; i += 256) v[i] = wgmax[(size_t)i * kStreamQ + ql];
+    for (int i = threadIdx.x; i < G; i += 256) v[i] = wgmax[(size_t)i * qcap + ql];
     __syncthreads();
     for (int i = threadIdx.x; i < G; i += 256) {
         const unsigned me = v[i];
@@ -1040,6 +1040,111 @@ mips_screenk_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, co
     }
 }
 
+// ---- the screen-k kernel with 32 queries per wave (256 per pass): see mips_screen32_kernel for the tile and mips_screenk_kernel
+// for the list protocol. Two lanes (l, l + 32) share a query; a stage's appends are issued at once (the one-ballot fast path makes
+// stages with a hit the exception, so the stores rarely sit between the DMA batches of the counted vmcnt wait).
+template <int NKB, bool BF>
+__global__ void __launch_bounds__(512, 2)
+mips_screenk32_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, const char* __restrict__ Qhi, const float* __restrict__ qbound,
+                      const float* __restrict__ tau0, int nq, u64* __restrict__ cand /* [G][kWideQ][kScreenKCap] */, int* __restrict__ cand_cnt, int k,
+                      int* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int SB_BYTES = 2 * NKB * kFragBytes;
+    constexpr int CPW = NKB / 4;
+    constexpr int NS = 2 * NKB;
+    constexpr int E = kScreenKCap / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = gridDim.x, b = blockIdx.x;
+    const int n_it = (n_sb - b + G - 1) / G;  // >= 1 (grid <= n_sb)
+
+    issue_super_block<NKB>(Xhi, b, lds, wave, lane);
+    if (n_it > 1) issue_super_block<NKB>(Xhi, b + G, lds + SB_BYTES, wave, lane);
+
+    const bool wave_active = wave * 32 < nq;
+    const int l31 = lane & 31, lh = lane >> 5;
+    half8 qf[NS];
+    {
+        const size_t qrow = (size_t)wave * 32 + l31;
+        const char* qp = Qhi + (qrow >> 4) * ((size_t)NKB * kFragBytes) + (qrow & 15) * 16 + lh * 256;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) qf[sl] = *(const half8*)(qp + (sl >> 1) * kFragBytes + (sl & 1) * 512);
+    }
+    const int qlocal = wave * 32 + l31;
+    const bool q_valid = qlocal < nq;
+    float band2 = q_valid ? 2.f * qbound[qlocal] : 0.f;
+    float tau = q_valid ? tau0[qlocal] - band2 : INFINITY;
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) asm volatile("" : "+v"(qf[sl]));
+    asm volatile("" : "+v"(band2), "+v"(tau));
+    u64* wave_lists = cand + ((size_t)b * kWideQ + (size_t)wave * 32) * kScreenKCap;
+    u64* my_list = wave_lists + (size_t)l31 * kScreenKCap;
+    int cnt = 0;  // entries in this lane's query list; replicated in the two lanes that share the query
+    const int rd_off = ((lane >> 4) & 1) * (NKB * kFragBytes) + lh * 256 + (lane & 15) * 16;
+
+    for (int it = 0; it < n_it; ++it) {
+        if (it + 1 < n_it)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 2 < n_it) issue_super_block<NKB>(Xhi, b + (it + 2) * G, lds + ((it + 2) % 3) * SB_BYTES, wave, lane);
+        if (!wave_active) continue;
+
+        const char* p = lds + (it % 3) * SB_BYTES + rd_off;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        constexpr int PF = 3;
+        half8 xa[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) xa[i] = *(const half8*)(p + (i >> 1) * kFragBytes + (i & 1) * 512);
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const half8 cur = xa[sl % PF];
+            if (sl + PF < NS) xa[sl % PF] = *(const half8*)(p + ((sl + PF) >> 1) * kFragBytes + ((sl + PF) & 1) * 512);
+            acc = mfma32<BF>(cur, qf[sl], acc);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            if (sl + PF < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        float m16 = acc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m16 = fmaxf(m16, acc[r]);
+        if (__ballot(q_valid && m16 >= tau) == 0ull) continue;  // nothing of this super-block can enter any list (tau = +inf for padding lanes)
+        const unsigned row0 = (unsigned)(b + it * G) * 32u + 4u * (unsigned)lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sc = acc[r];
+            const unsigned row = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
+            const bool hit = q_valid && (long long)row < n_rows && sc >= tau;
+            const u64 m = __ballot(hit);
+            if (m) {  // wave-uniform
+                const u64 grp = (m >> l31) & 0x0000000100000001ull;  // the two lanes of this query
+                const int slot = cnt + (lh ? (int)(grp & 1ull) : 0);
+                if (hit && slot < kScreenKCap) my_list[slot] = make_key(sc, row);
+                cnt += __popcll(grp);
+            }
+        }
+        unsigned m32 = (unsigned)(__ballot(cnt > kScreenKCap - 32) & 0xFFFFFFFFull);
+        while (m32) {  // rare: a list is about to run full -> prune it to (its k-th largest) - 2B
+            const int qi = __builtin_ctz(m32);
+            m32 &= m32 - 1;
+            int nc;
+            const u64 t = wave_select_band<E>(wave_lists + (size_t)qi * kScreenKCap, __shfl(cnt, qi), k, __shfl(band2, qi), lane, &nc, overflow);
+            if (l31 == qi) {
+                cnt = nc;
+                tau = fmaxf(tau, key_score(t) - band2);
+            }
+        }
+    }
+    if (wave_active && lane < 32) cand_cnt[(size_t)b * kWideQ + qlocal] = cnt;
+}
+
 // One 256-thread block per query: union of the G lists -> h_k (k-th largest s_hi) -> band survivors -> exact scores
 // (16 lanes per survivor, both planes) -> the k best by (exact score desc, id asc). Raises *overflow (and returns;
 // the exact fallback pass then rewrites D/I) when the union or the band does not fit.
@@ -1047,7 +1152,7 @@ template <bool BF>
 __global__ void __launch_bounds__(256)
 merge_screenk_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_cnt, int G, int k, const float* __restrict__ qbound,
                      const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, float* __restrict__ D,
-                     long long* __restrict__ I, long long id_offset, int* __restrict__ overflow) {
+                     long long* __restrict__ I, long long id_offset, int* __restrict__ overflow, int qcap /* queries per group: list stride */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     u64* keys = (u64*)lds;  // [kMergeKLds]
     __shared__ u64 surv[kSurvMax];
@@ -1060,7 +1165,7 @@ merge_screenk_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_
     const float band2 = 2.f * qbound[ql];
 
     int total = 0;
-    for (int w = tid; w < G; w += 256) total += cand_cnt[(size_t)w * kStreamQ + ql];
+    for (int w = tid; w < G; w += 256) total += cand_cnt[(size_t)w * qcap + ql];
     total = block_sum_256(total, red);
     if (tid == 0) { s_n = 0; atomicAdd(overflow + 1, total); }  // telemetry: candidates the main pass handed over (sctl[1])
     __syncthreads();
@@ -1074,8 +1179,8 @@ merge_screenk_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_
         return;
     }
     for (int w = 0; w < G; ++w) {
-        const int c = cand_cnt[(size_t)w * kStreamQ + ql];
-        const u64* lst = cand + ((size_t)w * kStreamQ + ql) * kScreenKCap;
+        const int c = cand_cnt[(size_t)w * qcap + ql];
+        const u64* lst = cand + ((size_t)w * qcap + ql) * kScreenKCap;
         for (int i = tid; i < c; i += 256) keys[atomicAdd(&s_n, 1)] = lst[i];
     }
     __syncthreads();
@@ -1474,7 +1579,8 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     size_t lists = p.lists_stream ? (size_t)p.Gx * kStreamQ * kStreamCap : (p.lists_generic ? (size_t)p.Gg * kGenericQ * kGenericCap : 0);
     size_t slots = p.lists_stream ? (size_t)p.Gx * kStreamQ : (p.lists_generic ? (size_t)p.Gg * kGenericQ : 0);
     if (screenk) {
-        const size_t l2 = (size_t)p.G * kStreamQ * kScreenKCap, s2 = (size_t)p.G * kStreamQ;
+        const size_t qc = wide_pass(nq) ? kWideQ : kStreamQ;
+        const size_t l2 = (size_t)p.G * qc * kScreenKCap, s2 = (size_t)p.G * qc;
         lists = lists > l2 ? lists : l2;
         slots = slots > s2 ? slots : s2;
     }
@@ -1602,12 +1708,52 @@ int run_screenk(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
         MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * kStreamQ * 4, st));
         hipLaunchKernelGGL((mips_screen_kernel<NKB, 2, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg, nqg,
                            gi * kStreamQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr);
-        hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G, k, tg);
+        hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G, k, tg, kStreamQ);
         hipLaunchKernelGGL((mips_screenk_kernel<NKB, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg,
                            (const float*)tg, nqg, cand, cnt, k, sctl);
         hipLaunchKernelGGL((merge_screenk_kernel<BF>), dim3(nqg), dim3(256), merge_lds, st, (const u64*)cand, (const int*)cnt, p.G, k, bg, (const char*)h->hi,
                            (const char*)h->lo, h->nkb, q_dev + (size_t)gi * kStreamQ * h->d, D_dev + (size_t)gi * kStreamQ * k,
-                           I_dev + (size_t)gi * kStreamQ * k, id_offset, sctl);
+                           I_dev + (size_t)gi * kStreamQ * k, id_offset, sctl, kStreamQ);
+        MDR_HIP_TRY(hipGetLastError());
+    }
+    return MDR_OK;
+}
+
+// 2 <= k <= 128 with more than 128 queries: groups of 256 on the 32-queries-per-wave kernels
+template <bool BF>
+int run_screenk32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, int k, const char* qhi, float* D_dev, long long* I_dev,
+                  long long id_offset, hipStream_t st) {
+    constexpr int NKB = 24;
+    const size_t lds_bytes = 3 * (size_t)NKB * 2 * kFragBytes;
+    const size_t merge_lds = (size_t)kMergeKLds * 8;
+    int rc_ = ensure_dynamic_lds((const void*)mips_screen32_kernel<NKB, 2, BF>, (int)lds_bytes);
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screenk32_kernel<NKB, BF>, (int)lds_bytes);
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)merge_screenk_kernel<BF>, (int)merge_lds);
+    if (rc_) return rc_;
+    float* bound = (float*)(ws + p.off_bound);
+    float* tau0 = (float*)(ws + p.off_gmax);
+    unsigned* wgmax = (unsigned*)(ws + p.off_scand);
+    int* sctl = (int*)(ws + p.off_sctl);
+    u64* cand = (u64*)(ws + p.off_cand);
+    int* cnt = (int*)(ws + p.off_cnt);
+    const int ngroups = (nq + kWideQ - 1) / kWideQ;
+    const int n_sb = (int)((h->ntotal + 31) / 32);
+    const size_t qgroup_bytes = (size_t)kWideQ * h->d * 2;
+    MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int nqg = nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ;
+        const char* qg = qhi + gi * qgroup_bytes;
+        const float* bg = bound + (size_t)gi * kWideQ;
+        float* tg = tau0 + (size_t)gi * kWideQ;
+        MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * kWideQ * 4, st));
+        hipLaunchKernelGGL((mips_screen32_kernel<NKB, 2, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg, nqg,
+                           gi * kWideQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr);
+        hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G, k, tg, kWideQ);
+        hipLaunchKernelGGL((mips_screenk32_kernel<NKB, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg,
+                           (const float*)tg, nqg, cand, cnt, k, sctl);
+        hipLaunchKernelGGL((merge_screenk_kernel<BF>), dim3(nqg), dim3(256), merge_lds, st, (const u64*)cand, (const int*)cnt, p.G, k, bg, (const char*)h->hi,
+                           (const char*)h->lo, h->nkb, q_dev + (size_t)gi * kWideQ * h->d, D_dev + (size_t)gi * kWideQ * k,
+                           I_dev + (size_t)gi * kWideQ * k, id_offset, sctl, kWideQ);
         MDR_HIP_TRY(hipGetLastError());
     }
     return MDR_OK;
@@ -1728,7 +1874,7 @@ int mdr_index_queries_per_pass(const mdr_index* h, int nq, int k) {
     if (!h || k < 1 || k > kKMax || nq < 1) return 0;
     const int path = make_plan(h, nq, k).path;
     if (path == PATH_GENERIC) return kGenericQ;
-    return path == PATH_SCREEN && k == 1 && wide_pass(nq) ? kWideQ : kStreamQ;
+    return path == PATH_SCREEN && wide_pass(nq) ? kWideQ : kStreamQ;
 }
 
 size_t mdr_index_search_workspace_bytes(const mdr_index* h, int nq, int k) {
@@ -1832,11 +1978,17 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
     // 2 <= k <= 128
     const int* run_if = nullptr;
     if (p.path == PATH_SCREEN) {
-        rc = bf ? run_screenk<true>(h, p, ws, q_dev, nq, k, qhi, D_dev, I_ll, id_offset, st)
-                : run_screenk<false>(h, p, ws, q_dev, nq, k, qhi, D_dev, I_ll, id_offset, st);
+        if (wide_pass(nq)) {
+            rc = bf ? run_screenk32<true>(h, p, ws, q_dev, nq, k, qhi, D_dev, I_ll, id_offset, st)
+                    : run_screenk32<false>(h, p, ws, q_dev, nq, k, qhi, D_dev, I_ll, id_offset, st);
+            h->last_kernel = bf ? "mips_screenk32_kernel<24,bf16>" : "mips_screenk32_kernel<24>";
+        } else {
+            rc = bf ? run_screenk<true>(h, p, ws, q_dev, nq, k, qhi, D_dev, I_ll, id_offset, st)
+                    : run_screenk<false>(h, p, ws, q_dev, nq, k, qhi, D_dev, I_ll, id_offset, st);
+            h->last_kernel = bf ? "mips_screenk_kernel<24,bf16>" : "mips_screenk_kernel<24>";
+        }
         if (rc) return rc;
         run_if = (const int*)(ws + p.off_sctl);  // exact pass below: only if a list or the band overflowed
-        h->last_kernel = bf ? "mips_screenk_kernel<24,bf16>" : "mips_screenk_kernel<24>";
         if (bf) return run_generic<true>(h, p, ws, q_dev, nq, k, D_dev, I_ll, id_offset, run_if, st);
     } else {
         h->last_kernel = "mips_stream_kernel<24,1>";

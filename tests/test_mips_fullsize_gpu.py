@@ -112,7 +112,7 @@ def test_five_million_rows_planted_and_brute_force(five_million, storage, tol, k
 
 @pytest.mark.parametrize("k", [8, 64])
 def test_bf16_nq800_against_generic_kernel_and_oracle(mdr, oracle, k):
-    """BASELINE configs[4], one shard's view: bf16 rows, 800 queries (beam 8 x 100 questions) in seven passes of 128."""
+    """BASELINE configs[4], one shard's view: bf16 rows, 800 queries (beam 8 x 100 questions) in four passes of 256 (32 queries per wave)."""
     n = 200_000
     xb = chunk(0, rows=n, seed=901)
     idx = mdr.IndexFlatIP(D_, storage="bf16")
@@ -121,7 +121,7 @@ def test_bf16_nq800_against_generic_kernel_and_oracle(mdr, oracle, k):
     q = torch.randn((800, D_), generator=g, device="cuda")
     q[::7] = xb[torch.arange(0, 800, 7, device="cuda") * 13] + 0.1 * q[::7]
     D, I = idx.search_device(q, k)
-    assert "mips_screenk_kernel" in idx.last_kernel()
+    assert "mips_screenk32_kernel" in idx.last_kernel()  # 800 queries: 256 per corpus pass
     idx.set_variant(1)
     try:
         Dg, Ig = idx.search_device(q, k)
