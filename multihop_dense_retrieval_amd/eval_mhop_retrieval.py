@@ -58,6 +58,8 @@ def build_parser():
     # extension (not in the reference): build the hop-2 inputs on the device from a token arena of the corpus
     # (tokenised once, cached next to the corpus dict) instead of host dict lookups + tokenizer between the hops
     p.add_argument("--hop2-on-device", action="store_true")
+    # extension: software-pipelined batch loop (hop 2 of batch i beside hop 1 of batch i+1; identical results)
+    p.add_argument("--pipeline-batches", action="store_true")
     return p
 
 
@@ -195,36 +197,76 @@ def main(argv=None, tokenizer=None):
     questions = [mhop.strip_question(it["question"]) for it in ds_items]
     metrics, retrieval_outputs = [], []
     roberta = "roberta" in args.model_name
-    for b_start in range(0, len(questions), args.batch_size):
-        with torch.no_grad():
-            batch_q = questions[b_start:b_start + args.batch_size]
-            batch_ann = ds_items[b_start:b_start + args.batch_size]
-            enc = move_to_cuda(dict(_tokenize(tokenizer, batch_q, None, args.max_q_len)))
-            q_embeds = model.encode_q(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids", None))
-            D, I = index.search(q_embeds, args.beam_size)
-            if arena is not None:
-                # questions re-encoded without the hop-1 length cap so the pair sees the same tokens the tokenizer would
-                qfull = move_to_cuda(dict(_tokenize(tokenizer, batch_q, None, args.max_q_sp_len)))
-                ids2, mask2 = arena.assemble_hop2(qfull["input_ids"], qfull["attention_mask"], I, D, args.max_q_sp_len)
-                q_sp_embeds = model.encode_q(ids2, mask2, None)
-                D, I = D.cpu().numpy(), I.cpu().numpy()
-            else:
-                D, I = D.cpu().numpy(), I.cpu().numpy()
-                pairs = mhop.build_hop2_pairs(batch_q, D, I, id2doc, roberta=roberta)
-                enc2 = move_to_cuda(dict(_tokenize(tokenizer, None, pairs, args.max_q_sp_len)))
-                q_sp_embeds = model.encode_q(enc2["input_ids"], enc2["attention_mask"], enc2.get("token_type_ids", None))
-            D_, I_ = index.search(q_sp_embeds, args.beam_size)
-            D_, I_ = D_.cpu().numpy(), I_.cpu().numpy()
 
-            chains = mhop.rank_paths(D, I, D_, I_, args.beam_size, args.topk)
-            for ann, ch in zip(batch_ann, chains):
-                if args.only_eval_ans:  # answer-string recall over the retrieved chains; nothing is saved (:208-217)
-                    metrics.append(answer_recall.answer_metrics(ann, ch, id2doc))
-                    continue
-                m = mhop.question_metrics(ch, ann["sp"], id2doc)
-                m.update(question=ann["question"], type=ann["type"])
-                metrics.append(m)
-                retrieval_outputs.append(mhop.output_record(ann, ch, id2doc))
+    def hop1_inputs(batch_q):
+        return move_to_cuda(dict(_tokenize(tokenizer, batch_q, None, args.max_q_len)))
+
+    def hop2_embeds(batch_q, D, I):
+        """Hop-2 query embeddings of one batch from its hop-1 results (device tensors). Returns (q_sp_embeds, D, I as numpy);
+        D carries the -inf of empty passages afterwards, as in the reference (:162-165)."""
+        if arena is not None:
+            # questions re-encoded without the hop-1 length cap so the pair sees the same tokens the tokenizer would
+            qfull = move_to_cuda(dict(_tokenize(tokenizer, batch_q, None, args.max_q_sp_len)))
+            ids2, mask2 = arena.assemble_hop2(qfull["input_ids"], qfull["attention_mask"], I, D, args.max_q_sp_len)
+            return model.encode_q(ids2, mask2, None), D.cpu().numpy(), I.cpu().numpy()
+        D, I = D.cpu().numpy(), I.cpu().numpy()
+        pairs = mhop.build_hop2_pairs(batch_q, D, I, id2doc, roberta=roberta)
+        enc2 = move_to_cuda(dict(_tokenize(tokenizer, None, pairs, args.max_q_sp_len)))
+        return model.encode_q(enc2["input_ids"], enc2["attention_mask"], enc2.get("token_type_ids", None)), D, I
+
+    def finish_batch(batch_ann, D, I, D_, I_):
+        chains = mhop.rank_paths(D, I, D_, I_, args.beam_size, args.topk)
+        for ann, ch in zip(batch_ann, chains):
+            if args.only_eval_ans:  # answer-string recall over the retrieved chains; nothing is saved (:208-217)
+                metrics.append(answer_recall.answer_metrics(ann, ch, id2doc))
+                continue
+            m = mhop.question_metrics(ch, ann["sp"], id2doc)
+            m.update(question=ann["question"], type=ann["type"])
+            metrics.append(m)
+            retrieval_outputs.append(mhop.output_record(ann, ch, id2doc))
+
+    starts = list(range(0, len(questions), args.batch_size))
+    if not args.pipeline_batches:
+        for b_start in starts:
+            with torch.no_grad():
+                batch_q = questions[b_start:b_start + args.batch_size]
+                batch_ann = ds_items[b_start:b_start + args.batch_size]
+                enc = hop1_inputs(batch_q)
+                q_embeds = model.encode_q(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids", None))
+                D, I = index.search(q_embeds, args.beam_size)
+                q_sp_embeds, D, I = hop2_embeds(batch_q, D, I)
+                D_, I_ = index.search(q_sp_embeds, args.beam_size)
+                finish_batch(batch_ann, D, I, D_.cpu().numpy(), I_.cpu().numpy())
+    elif starts:
+        # Software-pipelined loop (same results, batch for batch): batches are independent, so while batch i is in hop 2 the
+        # questions of batch i+1 are encoded on a side stream (second encoder lane) and ONE search call serves the hop-2
+        # queries of batch i together with the hop-1 queries of batch i+1 (more than 128 queries go 256 per corpus pass).
+        side = torch.cuda.Stream()
+        with torch.no_grad():
+            bq = questions[starts[0]:starts[0] + args.batch_size]
+            enc = hop1_inputs(bq)
+            D, I = index.search(model.encode_q(enc["input_ids"], enc["attention_mask"], None), args.beam_size)
+            for n, b_start in enumerate(starts):
+                batch_q = questions[b_start:b_start + args.batch_size]
+                batch_ann = ds_items[b_start:b_start + args.batch_size]
+                nxt = questions[starts[n + 1]:starts[n + 1] + args.batch_size] if n + 1 < len(starts) else None
+                q_next = None
+                if nxt is not None:
+                    enc_n = hop1_inputs(nxt)
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        q_next = model.encode_q(enc_n["input_ids"], enc_n["attention_mask"], None, lane=1)
+                q_sp_embeds, Dn, In = hop2_embeds(batch_q, D, I)
+                nsp = q_sp_embeds.shape[0]
+                if q_next is not None:
+                    torch.cuda.current_stream().wait_stream(side)
+                    q_next.record_stream(torch.cuda.current_stream())
+                    Dc, Ic = index.search(torch.cat([q_sp_embeds, q_next], 0), args.beam_size)
+                else:
+                    Dc, Ic = index.search(q_sp_embeds, args.beam_size)
+                finish_batch(batch_ann, Dn, In, Dc[:nsp].cpu().numpy(), Ic[:nsp].cpu().numpy())
+                if q_next is not None:
+                    D, I = Dc[nsp:].contiguous(), Ic[nsp:].contiguous()
 
     if args.save_path != "" and rank == 0:
         with open(args.save_path, "w") as out:
