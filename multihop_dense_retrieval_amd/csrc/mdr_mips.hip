@@ -664,6 +664,37 @@ __device__ __forceinline__ f32x16 mfma32(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// The 2*NKB-step accumulate chain of one 32-row super-block: acc = sum_s A_s(LDS) x qf[s]. hipcc waits lgkmcnt(0) in front of
+// every group of four MFMAs here (all reads in flight, the newest issued one instruction earlier: ~100 exposed cycles per 128
+// of matrix work), so the LDS reads and their waits are hand-placed: PF reads in flight, `s_waitcnt lgkmcnt(PF-1)` retires
+// exactly the oldest one before the MFMA that consumes it, the freed registers are refilled at once. The MFMAs stay compiler
+// builtins (hazards and accumulator allocation are hipcc's); each wait names the fragment it retires as an in/out operand, which
+// pins MFMA s behind wait s, and the refill behind MFMA s (guide §5.7, form ii). No other LDS / scalar-memory operation may
+// sit inside this region (checked in the .s: none), else the counts would be off.
+template <int NKB, bool BF>
+__device__ __forceinline__ f32x16 mfma_chain32(const char* p, const half8 (&qf)[2 * NKB]) {
+    constexpr int NS = 2 * NKB, PF = 4;
+    const unsigned a = (unsigned)(uintptr_t)p;  // LDS byte address (low 32 bits of the flat pointer)
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    half8 xa[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[i]) : "v"(a), "n"((i >> 1) * kFragBytes + (i & 1) * 512));
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+        const int left = NS - 1 - sl < PF - 1 ? NS - 1 - sl : PF - 1;  // reads younger than the one needed now
+        if (left == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xa[sl % PF]));
+        else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xa[sl % PF]));
+        else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xa[sl % PF]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[sl % PF]));
+        acc = mfma32<BF>(xa[sl % PF], qf[sl], acc);
+        if (sl + PF < NS)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[sl % PF]) : "v"(a), "n"(((sl + PF) >> 1) * kFragBytes + ((sl + PF) & 1) * 512));
+    }
+    return acc;
+}
+
 template <int NKB, int MODE, bool BF>
 __global__ void __launch_bounds__(512, 2)
 mips_screen32_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, const char* __restrict__ Qhi, const float* __restrict__ qbound, int nq,
@@ -735,25 +766,7 @@ mips_screen32_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, c
         if (!wave_active) continue;
 
         const char* p = lds + (it % 3) * SB_BYTES + rd_off;
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        constexpr int PF = 3;  // LDS reads run PF slices ahead of the MFMAs that consume them (issue order pinned below)
-        half8 xa[PF];
-#pragma unroll
-        for (int i = 0; i < PF; ++i) xa[i] = *(const half8*)(p + (i >> 1) * kFragBytes + (i & 1) * 512);
-#pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            const half8 cur = xa[sl % PF];
-            if (sl + PF < NS) xa[sl % PF] = *(const half8*)(p + ((sl + PF) >> 1) * kFragBytes + ((sl + PF) & 1) * 512);
-            acc = mfma32<BF>(cur, qf[sl], acc);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
-#pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            if (sl + PF < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
+        const f32x16 acc = mfma_chain32<NKB, BF>(p, qf);
         const unsigned row0 = (unsigned)(b + it * sG) * 32u + 4u * (unsigned)lh;
         const float cut = known - band2;
         // Fast path: a super-block that lies completely inside the corpus and holds no score above the cut (almost all of
@@ -1093,25 +1106,7 @@ mips_screenk32_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, 
         if (!wave_active) continue;
 
         const char* p = lds + (it % 3) * SB_BYTES + rd_off;
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        constexpr int PF = 3;
-        half8 xa[PF];
-#pragma unroll
-        for (int i = 0; i < PF; ++i) xa[i] = *(const half8*)(p + (i >> 1) * kFragBytes + (i & 1) * 512);
-#pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            const half8 cur = xa[sl % PF];
-            if (sl + PF < NS) xa[sl % PF] = *(const half8*)(p + ((sl + PF) >> 1) * kFragBytes + ((sl + PF) & 1) * 512);
-            acc = mfma32<BF>(cur, qf[sl], acc);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
-#pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            if (sl + PF < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
+        const f32x16 acc = mfma_chain32<NKB, BF>(p, qf);
         float m16 = acc[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) m16 = fmaxf(m16, acc[r]);

@@ -61,19 +61,44 @@ def shard_range(n, world, rank):
 def predict(model, eval_dataloader, out, out_bf16=None, to_device=move_to_cuda):
     """reference :95-113 -- batches -> model(batch)['embed'] -> rows of `out` (streamed into the memory-mapped matrix, not
     torch.cat'ed in host RAM). The loader yields windows of (row indices, batch) pairs (LengthBucketCollate).
-    out_bf16 (optional): a uint16 matrix receiving the same rows rounded to bf16 (round-to-nearest-even bit patterns)."""
+    out_bf16 (optional): a uint16 matrix receiving the same rows rounded to bf16 (round-to-nearest-even bit patterns).
+    The device -> host copy and the host-side write of batch i overlap the forward of batch i+1 (pinned staging buffer + event);
+    the reference's `.cpu()` per batch serialises them."""
     model.eval()
     n = 0
+    pending = None
+
+    def flush(p):
+        rows, host, host16, ev = p
+        if ev is not None:
+            ev.synchronize()
+        out[rows.numpy()] = host.numpy()
+        if host16 is not None:
+            out_bf16[rows.numpy()] = host16.numpy().view(np.uint16)
+
     for window in eval_dataloader:
         for rows, batch in window:
             batch_to_feed = to_device(batch)
             with torch.no_grad():
                 e = model(batch_to_feed)["embed"]
-                embed = e.cpu().numpy()
+            if e.is_cuda:
+                host = torch.empty(e.shape, dtype=e.dtype, pin_memory=True)
+                host.copy_(e, non_blocking=True)
+                host16 = None
                 if out_bf16 is not None:
-                    out_bf16[rows.numpy()] = e.to(torch.bfloat16).view(torch.int16).cpu().numpy().view(np.uint16)
-            out[rows.numpy()] = embed
-            n += embed.shape[0]
+                    host16 = torch.empty(e.shape, dtype=torch.int16, pin_memory=True)
+                    host16.copy_(e.to(torch.bfloat16).view(torch.int16), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            else:  # CPU stand-in encoders of the tests
+                host, ev = e, None
+                host16 = e.to(torch.bfloat16).view(torch.int16) if out_bf16 is not None else None
+            if pending is not None:
+                flush(pending)
+            pending = (rows, host, host16, ev)
+            n += int(e.shape[0])
+    if pending is not None:
+        flush(pending)
     return n
 
 
