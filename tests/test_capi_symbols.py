@@ -68,3 +68,22 @@ def test_product_package_never_imports_the_oracle():
     # the native sources must not link or include it either
     for path in glob.glob(os.path.join(pkg, "csrc", "*")):
         assert "oracle" not in open(path).read(), path
+
+
+def test_docs_cite_tests_and_files_that_exist():
+    """DESIGN.md / INTEGRATION.md name tests (`tests/x.py::test_y`) and files (`profiles/...`, `scripts/...`) as evidence: every
+    such reference must resolve, so the documents cannot drift from the tree (VERDICT r1 found a dangling test name)."""
+    import glob
+    missing = []
+    for doc in ("DESIGN.md", "INTEGRATION.md", "README.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        for path, name in re.findall(r"`(tests/[\w/]+\.py)::(\w+)", text):
+            src = open(os.path.join(ROOT, path)).read() if os.path.exists(os.path.join(ROOT, path)) else ""
+            if not re.search(rf"def {re.escape(name)}\w*\(", src):  # (the documents abbreviate long names with an ellipsis: prefix match)
+                missing.append(f"{doc}: {path}::{name}")
+        for path in re.findall(r"`((?:tests|scripts/gpu_|profiles|oracle|include)[\w./-]+?\.(?:py|sh|txt|csv|json|h|c|md))[`:]", text):
+            if "*" in path or "<" in path:
+                continue
+            if not os.path.exists(os.path.join(ROOT, path)):
+                missing.append(f"{doc}: {path}")
+    assert not missing, missing
