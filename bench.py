@@ -190,6 +190,43 @@ def verify_full_size(out, lo, hi, n_total, d, device, beam, bf16_rows=False):
     return res
 
 
+def mips_roofline(pipe, local, args, d):
+    """Roofline entry of the MIPS kernel from the timed search calls of `pipe`: PHYSICAL HBM bytes / HIP-event time of each whole
+    search call / 8 TB/s (the fp32-equivalent "algorithmic" rate under its own key)."""
+    calls = pipe.search_calls()  # [(ms, nq)] of every timed local search (rank-local)
+    shard_bytes = local.stream_bytes()  # N_pad * d * 4 (fp32 index) or * 2 (bf16): the corpus read once (SURVEY.md §8d)
+    qpps = [local.queries_per_pass(nq, args.beam) for _, nq in calls]
+    passes = [max(1, -(-nq // qpp)) for (_, nq), qpp in zip(calls, qpps)]
+    qpp = max(qpps) if qpps else 0
+    tot_ms = sum(ms for ms, _ in calls)
+    alg_bytes = float(sum(shard_bytes * p for p in passes))
+    kname = local.last_kernel()
+    ratio, src = (1.0, "designed (no counter profile for this kernel / shape)")
+    if args.pmc_traffic is None:
+        for name, (r_, src_) in PMC_TRAFFIC_RATIO.items():
+            if name in kname and d == 768 and args.storage != "bf16":
+                ratio, src = r_, f"{src_} (measured FETCH_SIZE x 2 / algorithmic bytes = {r_})"
+        hbm_bytes = alg_bytes * ratio
+    else:
+        hbm_bytes, src = float(args.pmc_traffic) * len(calls), "--pmc-traffic"
+    n_calls = max(1, len(calls))
+    achieved = hbm_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+    alg_rate = alg_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": round(hbm_bytes / n_calls), "traffic_source": src,
+            "algorithmic_bytes_per_launch": round(alg_bytes / n_calls),
+            "algorithmic_GBps": round(alg_rate, 1),
+            "algorithmic_over_physical": round(alg_bytes / hbm_bytes, 3) if hbm_bytes > 0 else None,
+            "avg_launch_ms": round(tot_ms / n_calls, 4), "launches_timed": len(calls),
+            "queries_per_launch": round(float(np.mean([nq for _, nq in calls])), 1) if calls else 0,
+            "corpus_passes_per_launch": round(float(np.mean(passes)), 3) if passes else 0, "queries_per_pass": qpp,
+            "note": "achieved/frac = physical HBM bytes (rocprofv3 FETCH_SIZE, gfx950-corrected) / HIP-event time of the whole search call; "
+                    "the screen kernels stream only the fp16 hi plane, so the fp32-equivalent (algorithmic) rate is reported separately. "
+                    "Pipelined loop: one 256-query pass serves hop 2 of a batch and hop 1 of the next (MFMA-heavier, lower HBM fraction, half "
+                    "the passes); `sequential.mips_roofline` is the beam=1, 100-queries-per-call kernel the north star's HBM target names"}
+
+
 def build_pipeline(args, world, rank, device, dist, weak):
     from multihop_dense_retrieval_amd import index as mdr_index
     from multihop_dense_retrieval_amd import mhop
@@ -366,36 +403,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     qps = GB * args.steps / elapsed
 
-    # ---- roofline of the dominant MIPS kernel: PHYSICAL HBM bytes / HIP-event time of each search call ----------------
-    calls = pipe.search_calls()  # [(ms, nq)] of every timed local search (rank-local)
-    shard_bytes = local.stream_bytes()  # N_pad * d * 4 (fp32 index) or * 2 (bf16): the corpus read once
-    qpps = [local.queries_per_pass(nq, args.beam) for _, nq in calls]
-    passes = [max(1, -(-nq // qpp)) for (_, nq), qpp in zip(calls, qpps)]
-    qpp = max(qpps) if qpps else 0
-    tot_ms = sum(ms for ms, _ in calls)
-    alg_bytes = float(sum(shard_bytes * p for p in passes))
-    kname = local.last_kernel()
-    ratio, src = (1.0, "designed (no counter profile for this kernel / shape)")
-    if args.pmc_traffic is None:
-        for name, (r_, src_) in PMC_TRAFFIC_RATIO.items():
-            if name in kname and d == 768 and args.storage != "bf16":
-                ratio, src = r_, f"{src_} (measured FETCH_SIZE x 2 / algorithmic bytes = {r_})"
-        hbm_bytes = alg_bytes * ratio
-    else:
-        hbm_bytes, src = float(args.pmc_traffic) * len(calls), "--pmc-traffic"
-    n_calls = max(1, len(calls))
-    achieved = hbm_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
-    alg_rate = alg_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": round(hbm_bytes / n_calls), "traffic_source": src,
-                "algorithmic_bytes_per_launch": round(alg_bytes / n_calls),
-                "algorithmic_GBps": round(alg_rate, 1),
-                "algorithmic_over_physical": round(alg_bytes / hbm_bytes, 3) if hbm_bytes > 0 else None,
-                "avg_launch_ms": round(tot_ms / n_calls, 4), "launches_timed": len(calls),
-                "corpus_passes_per_launch": round(float(np.mean(passes)), 3) if passes else 0, "queries_per_pass": qpp,
-                "note": "achieved/frac = physical HBM bytes (rocprofv3 FETCH_SIZE, gfx950-corrected) / HIP-event time of the whole search call; "
-                        "the screen kernels stream only the fp16 hi plane, so the fp32-equivalent (algorithmic) rate is reported separately"}
+    roofline = mips_roofline(pipe, local, args, d)
 
     stage = pipe.stage_ms()
     result = {
@@ -452,7 +460,7 @@ def main():
             pipe_q.encoder, pipe_q.arena = pipe.encoder, pipe.arena  # same weights, same token arena
         _, el_q = timed_steps(pipe_q, args, world, device, dist)
         result["sequential"] = {"value": round(GB * args.steps / el_q, 2), "unit": "queries/s", "ms_per_step": round(el_q / args.steps * 1e3, 4),
-                                "stage_ms": pipe_q.stage_ms()}
+                                "stage_ms": pipe_q.stage_ms(), "mips_roofline": mips_roofline(pipe_q, local, args, d)}
         del pipe_q
 
     if world > 1 and weak and not args.no_strong:
