@@ -187,6 +187,10 @@ int mdr_assemble_hop2(const int64_t* q_ids_dev, const int64_t* q_mask_dev, int b
  * ---------------------------------------------------------------------------------------------- */
 int mdr_test_gemm_f16(const void* A_dev, const void* W_dev, const float* bias_dev, int M, const int* m_dev, int N, int K,
                       void* out_dev, int epilogue, int kernel, int device, void* stream);
+/* Measurement hook: the s_memtime timeline the persistent 256x256 GEMM accumulates when it is launched with the environment
+ * knob MDR_GEMM_ABL=5 (shader cycles of wave 0 summed over workgroups: [0] wait + barrier A, [1..3] sub-phases 1-3,
+ * [4] wait + barrier B, [5] sub-phase 4, [6] epilogue, [7] K-tiles counted); synchronises the device; reset != 0 clears it. */
+int mdr_test_gemm_stamps(unsigned long long* out8_host, int reset);
 
 #ifdef __cplusplus
 }

@@ -646,8 +646,12 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
 // its MFMAs whichever of DMA / MFMA / LDS reads was removed -- the barrier skeleton itself; removed.
 using GemmB2 = GemmCfg<256, 256, 2, 4, 2>;
 
-// ABL (measurement only, results are wrong for ABL != 0): 1 = no DMA after the prologue, 2 = no LDS fragment reads, 3 = no MFMAs,
+// ABL (measurement only, results are wrong for ABL != 0 except 5): 1 = no DMA after the prologue, 2 = no LDS fragment reads, 3 = no MFMAs,
 // 4 = no epilogue stores -- which of the CU's pipes the K-loop is waiting for (scripts/gpu_gemm_bench.py, MDR_GEMM_ABL).
+// 5 = correct results + an s_memtime timeline of wave 0 of every workgroup summed into g_gemm_stamp (mdr_test_gemm_stamps):
+// [0] wait + barrier A, [1] sub-phase 1 (incl. its fragment reads), [2] sub-phase 2, [3] sub-phase 3, [4] wait + barrier B,
+// [5] sub-phase 4, [6] epilogue, [7] K-tiles counted.
+__device__ unsigned long long g_gemm_stamp[8];
 template <int EPI, int ABL = 0>
 __global__ void __launch_bounds__(512)
 gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M_cap,
@@ -746,13 +750,24 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
         }
     };
     int kt = 0, tile = 0;
+    unsigned long long stamp_sum[7] = {0, 0, 0, 0, 0, 0, 0}, stamp_t = 0;
+    auto stamp = [&](int seg) __attribute__((always_inline)) {
+        if (ABL != 5) return;
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (seg >= 0) stamp_sum[seg] += now - stamp_t;
+        stamp_t = now;
+        __builtin_amdgcn_sched_barrier(0);
+    };
     for (int T = 0; T < total; ++T) {
         const char* slot = lds + (T & 1) * C::STAGE_BYTES;
         const bool first = kt == 0;
+        stamp(T == 0 ? -1 : 6);
         // barrier A: K-tile T landed (at most the 2 pieces issued in the previous sub-phase 4 may still fly)
         asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        stamp(0);
         // reads for sub-phases 1 and 2
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (ABL != 2) wf0[q] = *(const half8*)(slot + w_rd + q * 16 * 128 + sw0);
@@ -764,6 +779,7 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
         // ---- sub-phase 1: k-half 0, m-fragments 0-3; pieces 2,3 of the loader's K-tile (T+1)
         if (first) sub_phase(std::true_type{}, 0, wf0, af_a, 2);
         else sub_phase(std::false_type{}, 0, wf0, af_a, 2);
+        stamp(1);
         // reads for sub-phase 3 (k-half 1): W fragments, A fragments 0-3 into the registers sub-phase 1 just released
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (ABL != 2) wf1[q] = *(const half8*)(slot + w_rd + q * 16 * 128 + sw1);
@@ -773,6 +789,7 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
         // ---- sub-phase 2: k-half 0, m-fragments 4-7; pieces 4,5
         if (first) sub_phase(std::true_type{}, 4, wf0, af_b, 4);
         else sub_phase(std::false_type{}, 4, wf0, af_b, 4);
+        stamp(2);
         // reads for sub-phase 4: the LAST reads of this slot
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (ABL != 2) af_b[q] = *(const half8*)(slot + a_rd + (4 + q) * 16 * 128 + sw1);
@@ -780,12 +797,15 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
         // ---- sub-phase 3: k-half 1, m-fragments 0-3; pieces 6,7 complete K-tile T+1
         sub_phase(std::false_type{}, 0, wf1, af_a, 6);
         next_ktile();
+        stamp(3);
         // barrier B: every wave's reads of this slot have retired -> it may be refilled (K-tile T+2)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        stamp(4);
         // ---- sub-phase 4: k-half 1, m-fragments 4-7; pieces 0,1 of K-tile T+2
         sub_phase(std::false_type{}, 4, wf1, af_b, 0);
+        stamp(5);
         if (++kt == KT) {
             kt = 0;
             int m0, n0;
@@ -840,6 +860,14 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus pieces must have landed before the LDS is released
+    if (ABL == 5) {
+        stamp(6);
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) atomicAdd(&g_gemm_stamp[i], stamp_sum[i]);
+            atomicAdd(&g_gemm_stamp[7], (unsigned long long)total);
+        }
+    }
 }
 
 using GemmBig = GemmCfg<256, 256, 4, 2, 2>;
@@ -1278,7 +1306,7 @@ int launch_gemm_big(const _Float16* A, int lda, const _Float16* W, const float* 
         MDR_HIP_TRY(hipGetLastError());                                                                                           \
         return MDR_OK;                                                                                                            \
     }
-    MDR_BIG_ABL(1) MDR_BIG_ABL(2) MDR_BIG_ABL(3) MDR_BIG_ABL(4)
+    MDR_BIG_ABL(1) MDR_BIG_ABL(2) MDR_BIG_ABL(3) MDR_BIG_ABL(4) MDR_BIG_ABL(5)
 #undef MDR_BIG_ABL
     { int rc_ = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI>, lds); if (rc_) return rc_; }
     hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(grid), dim3(512), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo);
@@ -1477,6 +1505,17 @@ int mdr_test_gemm_f16(const void* A_dev, const void* W_dev, const float* bias_de
     if (epilogue == EPI_BIAS_F16) return launch_gemm<EPI_BIAS_F16>(A, K, W, bias_dev, M, m_dev, N, K, out_dev, N, nullptr, 0, M, ncu, st, nullptr, kernel);
     if (epilogue == EPI_BIAS_GELU_F16) return launch_gemm<EPI_BIAS_GELU_F16>(A, K, W, bias_dev, M, m_dev, N, K, out_dev, N, nullptr, 0, M, ncu, st, nullptr, kernel);
     return launch_gemm<EPI_BIAS_F32>(A, K, W, bias_dev, M, m_dev, N, K, out_dev, N, nullptr, 0, M, ncu, st, nullptr, kernel);
+}
+
+int mdr_test_gemm_stamps(unsigned long long* out8_host, int reset) {
+    MDR_REQUIRE(out8_host, "NULL pointer");
+    MDR_HIP_TRY(hipDeviceSynchronize());
+    MDR_HIP_TRY(hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_gemm_stamp), 8 * sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        MDR_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamp), z, sizeof(z)));
+    }
+    return MDR_OK;
 }
 
 int mdr_encoder_set_fill_hint(mdr_encoder* h, float fill) {

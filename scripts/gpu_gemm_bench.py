@@ -34,3 +34,11 @@ for name, N, K, epi in (("qkv", 2304, 768, 0), ("out", 768, 768, 3), ("ffn1", 30
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         print(f"{name:5s} M={M} N={N} K={K} kernel {kern}{'' if knob is None else ' ' + knob[0] + '=' + knob[1]}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
+        if os.environ.get("MDR_GEMM_ABL") == "5" and kern == 6:  # s_memtime timeline of wave 0, shader cycles per K-tile
+            import ctypes
+            buf = (ctypes.c_uint64 * 8)()
+            _lib.check(L.mdr_test_gemm_stamps(buf, 1))
+            kt = max(1, buf[7])
+            names = ("waitA+barA", "sp1", "sp2", "sp3", "waitB+barB", "sp4", "epilogue")
+            print("      cycles per K-tile (wave 0 mean): " + "  ".join(f"{n} {buf[i] / kt:7.1f}" for i, n in enumerate(names))
+                  + f"   total {sum(buf[:7]) / kt:7.1f}", flush=True)
