@@ -261,16 +261,40 @@ __global__ void f32_to_f16_kernel(const float* __restrict__ in, _Float16* __rest
 enum { EPI_BIAS_F16 = 0, EPI_BIAS_GELU_F16 = 1, EPI_BIAS_RES_F32 = 2, EPI_BIAS_F32 = 3 };
 constexpr int BK = 64;
 
-// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, branch-free): libm's erff costs ~60 divergent instructions
-// per value, which made the GELU epilogue as expensive as the MFMA loop of its tile.
-__device__ inline float erf_fast(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 1.f - poly * __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);  // raw v_exp_f32: the argument is <= 0, underflow to 0 is the right answer
-    return copysignf(e, x);
+// erf-GELU(x) = x Phi(x) with the normal tail written as a power of two: Phi(-a) = 2^-(1 + a P(a)), a = |x|, P a degree-5
+// polynomial fitted to -log2(erfc(a / sqrt 2)) / a on [0, 6], weighted by the tail itself (scripts/fit_gelu_tail.py; it
+// extrapolates monotonically beyond 6). max |Phi error| 2.1e-7, max |GELU error| 6.9e-7 over [-8, 8] evaluated in fp32
+// (the Abramowitz-Stegun 7.1.26 erf used before: 2.1e-7): 7 packed FMAs per PAIR of values + one v_exp_f32 + 4 simple ops
+// per value, against ~18 ops + v_rcp_f32 + v_exp_f32 per value. Measured (round 2, MDR_GEMM_ABL=5 timeline, FFN1 shape): the
+// epilogue of a 256x256 tile 16.4 k -> 14.0 k cycles, the kernel -3 % wall -- the GELU arithmetic was NOT what makes that
+// epilogue long (with GELU or without the kernel now takes the same time). libm's erff: ~60 divergent instructions per value.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// d = a * b + (c, c): hipcc scalarises a 2-vector FMA whose addend is a literal (VOP3P takes no literal), so the packed
+// form is spelled out with the constant pair in SGPRs
+__device__ inline f32x2 pk_fma_c(f32x2 a, f32x2 b, float c) {
+    f32x2 d;
+    const f32x2 cc = {c, c};
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(cc));
+    return d;
 }
-__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
+__device__ inline f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 a = __builtin_elementwise_abs(x);
+    f32x2 p = pk_fma_c(a, (f32x2){-1.982813420e-05f, -1.982813420e-05f}, 6.620948925e-04f);
+    p = pk_fma_c(p, a, -7.759194708e-03f);
+    p = pk_fma_c(p, a, 5.296392132e-02f);
+    p = pk_fma_c(p, a, 4.590664427e-01f);
+    p = pk_fma_c(p, a, 1.151119066e+00f);
+    const f32x2 e = pk_fma_c(p, a, 1.0f);
+    f32x2 t;
+    t[0] = __builtin_amdgcn_exp2f(-e[0]);  // Phi(-|x|); raw v_exp_f32: the argument is <= -1, underflow to 0 is the right answer
+    t[1] = __builtin_amdgcn_exp2f(-e[1]);
+    const f32x2 s = __builtin_elementwise_copysign(0.5f - t, x);  // Phi(x) - 1/2
+    return x * s + 0.5f * x;
+}
+__device__ inline f32x4 gelu_erf4(f32x4 x) {
+    const f32x2 lo = gelu_erf2((f32x2){x[0], x[1]}), hi = gelu_erf2((f32x2){x[2], x[3]});
+    return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+}
 
 template <int BM_, int BN_, int WGM_, int WGN_, int STAGES_>
 struct GemmCfg {
@@ -381,8 +405,7 @@ gemm_f16_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
             const f32x4 b4 = *(const f32x4*)(bias + n);
             f32x4 v = acc[mt][nt] + b4;
             if (EPI == EPI_BIAS_GELU_F16) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                v = gelu_erf4(v);
             }
             if (EPI == EPI_BIAS_RES_F32) {
                 const half4 r4 = *(const half4*)(res + (size_t)m * ldr + n);
@@ -605,8 +628,7 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
                 const f32x4 b4 = *(const f32x4*)(lds_bias + n);
                 f32x4 v = acc[mt][nt] + b4;
                 if (EPI == EPI_BIAS_GELU_F16) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    v = gelu_erf4(v);
                 }
                 if constexpr (F16OUT) {
                     half4 o;
@@ -831,8 +853,7 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
                         const f32x4 b4 = *(const f32x4*)(lds_bias + n);
                         f32x4 v = acc[mt][nt] + b4;
                         if (EPI == EPI_BIAS_GELU_F16) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                            v = gelu_erf4(v);
                         }
                         if constexpr (F16OUT) {
                             half4 o;
