@@ -96,12 +96,13 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
  *   out4_host[0] = 1 when the hi-plane screen gave up (a candidate list or the refinement band overflowed) and the exact
  *                  pass re-did the search, else 0;  [1] = candidates the screen pass handed to the exact re-scoring (k == 1: of the
  *                  last group of 128 queries; k > 1: summed over all queries of the call);  [2] = 1 when a query held a non-finite value;  [3] = path (1 generic,
- *                  2 exact stream, 3 screen). Results never depend on it: it lets the parity tests assert that adversarial
+ *                  2 exact stream, 3 screen) in its low byte, | 512 when the int8 screening tier ran in front of the fp16 screen, | 256 when
+ *                  one of that tier's candidate lists overflowed (the fp16 screen then ran behind it). Results never depend on it: it lets the parity tests assert that adversarial
  *                  inputs (all-ties corpora, large common mean) really took the fallback and benign ones did not. */
 int mdr_index_search_telemetry(const mdr_index* h, int nq, int k, const void* workspace_dev, int64_t* out4_host, void* stream);
 
 /* Test hook: force a kernel variant (0 = auto, 1 = generic fp32 reference kernel, 2 = exact MFMA stream kernel,
- * 3 = hi-plane screen + exact refinement, k == 1 only). */
+ * 3 = screen + exact refinement, 4 = the same without the int8 screening tier in front of the fp16 hi-plane screen). */
 int mdr_index_set_variant(mdr_index* h, int variant);
 /* Name of the kernel the last search dispatched to (for rocprof matching); static storage. */
 const char* mdr_index_last_kernel(const mdr_index* h);

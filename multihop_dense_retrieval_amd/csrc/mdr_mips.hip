@@ -495,7 +495,8 @@ template <int NKB, int MODE, bool BF>
 __global__ void __launch_bounds__(512, 2)
 mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, const char* __restrict__ Qhi, const float* __restrict__ qbound, int nq,
                    int q_base, unsigned* __restrict__ gmax /* [nq] ordered(max s_hi) */, u64* __restrict__ cand /* [waves][kWaveCandCap] */,
-                   int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow) {
+                   int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow, const int* __restrict__ run_if = nullptr) {
+    if (run_if && *run_if == 0) return;  // behind the int8 tier: only when one of its lists overflowed
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SB_BYTES = 2 * NKB * kFragBytes;
     constexpr int CPW = NKB / 4;
@@ -706,7 +707,9 @@ template <int NKB, int MODE, bool BF>
 __global__ void __launch_bounds__(512, 2)
 mips_screen32_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, const char* __restrict__ Qhi, const float* __restrict__ qbound, int nq,
                      int q_base, unsigned* __restrict__ gmax /* [nq] ordered(max s_hi); MODE 2: [G][kWideQ] */,
-                     u64* __restrict__ cand /* [waves][kWaveCandCap] */, int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow) {
+                     u64* __restrict__ cand /* [waves][kWaveCandCap] */, int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow,
+                     const int* __restrict__ run_if = nullptr) {
+    if (run_if && *run_if == 0) return;  // behind the int8 tier: only when one of its lists overflowed
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SB_BYTES = 2 * NKB * kFragBytes;
     constexpr int CPW = NKB / 4;
@@ -848,7 +851,8 @@ __device__ __forceinline__ float exact_dot16(const char* __restrict__ Xhi, const
 template <bool BF>
 __global__ void __launch_bounds__(256)
 mips_refine_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, const u64* __restrict__ cand,
-                   const int* __restrict__ cand_cnt, u64* __restrict__ best) {
+                   const int* __restrict__ cand_cnt, u64* __restrict__ best, const int* __restrict__ run_if = nullptr) {
+    if (run_if && *run_if == 0) return;
     const int n = cand_cnt[blockIdx.x];
     if (n == 0) return;
     const u64* list = cand + (size_t)blockIdx.x * kWaveCandCap;
@@ -1292,6 +1296,522 @@ mips_generic_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, 
 }
 
 // ---- result kernels ----------------------------------------------------------------------------------
+// =====================================================================================================================
+// int8 screening tier (k = 1, F32X2H storage): HALF the bytes of the fp16 hi plane per corpus pass.
+// Every row is stored a third time as int8 with its own scale, x_i = s_r (x8_i + e_i), |e_i| <= 1/2 (s_r = max_i|x_i| / 127),
+// every query is quantised the same way, q_i = t (q8_i + f_i), |f_i| <= 1/2, and v_mfma_i32_16x16x64_i8 accumulates
+// A = sum q8_i x8_i exactly. Then
+//     q.x = t s_r (A + sum q8_i e_i + sum f_i x8_i + sum f_i e_i),   |q.x - t s_r A| <= t s_r (L1(q8)/2 + L1(x8_r)/2 + d/4)
+// so with  alpha_q = t L1(q8) / 2  and  beta_q = t max_r [ s_r (L1(x8_r)/2 + d/4) ]  (the max is kept by add(), i8stats[1])
+//     L_r = s_r (t A - alpha_q) - beta_q  <=  q.x_r  <=  s_r (t A + alpha_q) + beta_q = U_r
+// (both inflated by 1e-3 for the fp32 roundings of the scales and of these two FMAs). A row can be the best row only if
+// U_r >= max_r' L_r'; the kernel keeps the running maximum of the lower bounds (`known`) exactly the way mips_screen_kernel keeps its
+// running s_hi, appends rows with U_r >= known to the same per-wave candidate lists, and mips_refine_kernel re-scores them from
+// the fp16 (hi, lo) planes: ids and scores are those of the exact path. If a list overflows (data for which the int8 bound is
+// loose: a large common mean, very heavy tails) the fp16 screen runs behind it, and the exact pass behind that -- each
+// skipped on the device when the tier before it did not overflow.
+// Layout: a super-block (32 rows) = 2 x NKB8 fragment blocks of 1 KiB (16 rows x 64 int8; lane (lr, g) of the MFMA owns the
+// 16 bytes k = 64 kb + 16 g .. of row lr at (16 g + lr) * 16) followed by 256 bytes holding the 32 row scales: 24.25 KiB at
+// d = 768 against the 48 KiB of the fp16 hi plane.
+#ifndef MDR_I8_ABL
+#define MDR_I8_ABL 0  // measurement builds (wrong results): 1 no scale-tail DMA, 2 no epilogue, 3 no MFMAs, 4 no fragment reads
+#endif
+constexpr int kI8RefinePerQuery = 2048;  // survivors per query of a pass beyond which the int8 tier hands over to the fp16 screen (see mips_refine8_kernel)
+constexpr int kI8Tail = 256;  // bytes behind a super-block's fragments: 32 fp32 row scales (+ padding to one 4-byte-per-lane DMA piece)
+#ifndef MDR_I8_ALIGN
+#define MDR_I8_ALIGN 256  // variant-build knob: alignment of a super-block's start in the int8 plane
+#endif
+__host__ __device__ inline size_t i8_sb_bytes(int nkb8) { return ((size_t)2 * nkb8 * kFragBytes + kI8Tail + MDR_I8_ALIGN - 1) / MDR_I8_ALIGN * MDR_I8_ALIGN; }
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// candidate of the int8 tier: query (16 bits) | upper bound U as the top 16 bits of its ordered representation, rounded UP | row
+__device__ inline u64 pack_cand8(int qi, float u, unsigned row) {
+    unsigned o = ord32(u);
+    o = o > 0xFFFF0000u ? 0xFFFFu : (o + 0xFFFFu) >> 16;
+    return ((u64)(unsigned)qi << 48) | ((u64)o << 32) | row;
+}
+
+__device__ inline float wave_max_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ inline int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one wave per row: lanes 0 .. d/16-1 quantise 16 consecutive columns each. stats[0] = max s_r, stats[1] = max s_r (L1(x8_r)/2 + d/4)
+// (non-negative floats, kept as their bit patterns: they order like ints)
+template <typename T>
+__global__ void __launch_bounds__(256) convert_to_i8_kernel(const T* __restrict__ src, long long n, int d, long long row0, char* __restrict__ dst,
+                                                            int* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int nkb8 = d >> 6;
+    const bool on = lane < (d >> 4);
+    float x[16];
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        x[j] = on ? load_as_f32<T>(src + r * (long long)d + lane * 16 + j) : 0.f;
+        mx = fmaxf(mx, fabsf(x[j]));
+    }
+    mx = wave_max_f(mx);
+    const float sc = mx > 0.f ? mx / 127.f : 0.f;
+    const float inv = mx > 0.f ? 127.f / mx : 0.f;
+    int l1 = 0;
+    i32x4 packed;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        unsigned u = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            int v = (int)rintf(x[4 * w + b] * inv);
+            v = v > 127 ? 127 : (v < -127 ? -127 : v);
+            l1 += v < 0 ? -v : v;
+            u |= ((unsigned)v & 0xFFu) << (8 * b);
+        }
+        packed[w] = (int)u;
+    }
+    l1 = wave_sum_i(l1);
+    const long long row = row0 + r;
+    char* sb = dst + (size_t)(row >> 5) * i8_sb_bytes(nkb8);
+    if (on) {
+        const int kb = lane >> 2, g = lane & 3;
+        *(i32x4*)(sb + ((size_t)((row >> 4) & 1) * nkb8 + kb) * kFragBytes + (g * 16 + (int)(row & 15)) * 16) = packed;
+    }
+    if (lane == 0) {
+        *(float*)(sb + (size_t)2 * nkb8 * kFragBytes + (row & 31) * 4) = sc;
+        const float c = sc * (0.5f * (float)l1 + 0.25f * (float)d);
+        if (__float_as_int(sc) > stats[0]) atomicMax(stats + 0, __float_as_int(sc));
+        if (__float_as_int(c) > stats[1]) atomicMax(stats + 1, __float_as_int(c));
+    }
+}
+
+// one wave per query row (rows >= nq: zero padding). q8: fragment-tiled like the corpus blocks (16 queries per block, NKB8 KiB
+// each); qab[i] = (t, alpha, beta, 0) with the 1e-3 inflation described above.
+__global__ void __launch_bounds__(256) prep_queries_i8_kernel(const float* __restrict__ q, int nq, int nq_pad, int d, const int* __restrict__ stats,
+                                                              char* __restrict__ q8, f32x4* __restrict__ qab) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nq_pad) return;
+    const int nkb8 = d >> 6;
+    const bool on = lane < (d >> 4) && i < nq;
+    float x[16];
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        x[j] = on ? q[(size_t)i * d + lane * 16 + j] : 0.f;
+        mx = fmaxf(mx, fabsf(x[j]));
+    }
+    mx = wave_max_f(mx);
+    const bool fin = mx <= 3.0e38f;  // a non-finite query gets an infinite bound below: every row becomes a candidate, the lists overflow, the tiers behind decide
+    const float t = mx > 0.f && fin ? mx / 127.f : 0.f;
+    const float inv = mx > 0.f && fin ? 127.f / mx : 0.f;
+    int l1 = 0;
+    i32x4 packed;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        unsigned u = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            int v = (int)rintf(x[4 * w + b] * inv);
+            v = v > 127 ? 127 : (v < -127 ? -127 : v);
+            l1 += v < 0 ? -v : v;
+            u |= ((unsigned)v & 0xFFu) << (8 * b);
+        }
+        packed[w] = (int)u;
+    }
+    l1 = wave_sum_i(l1);
+    if (lane < (d >> 4)) {
+        const int kb = lane >> 2, g = lane & 3;
+        *(i32x4*)(q8 + ((size_t)(i >> 4) * nkb8 + kb) * kFragBytes + (g * 16 + (i & 15)) * 16) = packed;
+    }
+    if (lane == 0) {
+        const float s2 = __int_as_float(stats[1]);
+        f32x4 o = {t, 0.5f * t * (float)l1 * 1.001f, t * s2 * 1.001f, 0.f};
+        if (!fin) o = (f32x4){0.f, INFINITY, INFINITY, 0.f};
+        qab[i] = o;
+    }
+}
+
+template <int NKB8>
+__device__ __forceinline__ void issue_super_block8(const char* __restrict__ X8, int sb, char* slot, int wave, int lane) {
+    constexpr int CPW = NKB8 / 4;  // 2 * NKB8 fragment pieces over 8 waves
+    const char* g = X8 + (size_t)sb * i8_sb_bytes(NKB8) + (size_t)wave * CPW * kFragBytes + lane * 16;
+    char* l = slot + wave * CPW * kFragBytes;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) __builtin_amdgcn_global_load_lds(MDR_GPTR(g + c * kFragBytes), MDR_LPTR(l + c * kFragBytes), 16, 0, MDR_MIPS_DMA_AUX);
+    if (wave == 0 && MDR_I8_ABL != 1)  // the scale tail: one 4-byte-per-lane piece
+        __builtin_amdgcn_global_load_lds(MDR_GPTR(X8 + (size_t)sb * i8_sb_bytes(NKB8) + 2 * NKB8 * kFragBytes + lane * 4),
+                                         MDR_LPTR(slot + 2 * NKB8 * kFragBytes), 4, 0, MDR_MIPS_DMA_AUX);
+}
+
+// MODE 0: sample pass (publish the largest lower bound per query to gmax); MODE 1: main pass (candidates). See mips_screen_kernel.
+template <int NKB8, int MODE, int NS>  // NS: LDS slots of one super-block (NS - 1 stages in flight)
+__global__ void __launch_bounds__(512, 2)
+mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, const char* __restrict__ Q8, const f32x4* __restrict__ qab, int nq, int q_base,
+                    unsigned* __restrict__ gmax /* [nq] ordered(max L) */, u64* __restrict__ cand /* [waves][kWaveCandCap] */,
+                    int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int SB_BYTES = 2 * NKB8 * kFragBytes + kI8Tail;
+    constexpr int CPW = NKB8 / 4;  // DMA pieces per wave and stage (wave 0: + 1, the scale tail)
+    constexpr int HK = NKB8 / 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = gridDim.x, b = blockIdx.x;
+    int n_it = (n_sb - b + G - 1) / G;  // >= 1 (grid <= n_sb)
+    if (MODE == 0 && n_it > kSampleStages) n_it = kSampleStages;
+
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i)
+        if (i < n_it) issue_super_block8<NKB8>(X8, b + i * G, lds + i * SB_BYTES, wave, lane);
+
+    const bool wave_active = wave * 16 < nq;
+    i32x4 qh[NKB8];
+    {
+        const size_t qoff = (size_t)wave * NKB8 * kFragBytes + lane * 16;
+#pragma unroll
+        for (int kb = 0; kb < NKB8; ++kb) qh[kb] = *(const i32x4*)(Q8 + qoff + kb * kFragBytes);
+    }
+    const int qlocal = wave * 16 + (lane & 15);
+    const bool q_valid = qlocal < nq;
+    f32x4 ab = {0.f, 0.f, 0.f, 0.f};
+    if (q_valid) ab = qab[qlocal];
+    float qt = ab[0], qa = ab[1], qb = ab[2];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float known = -FLT_MAX;  // largest lower bound known for this lane's query
+    if (MODE == 1 && q_valid) {
+        unsigned g = gmax[qlocal];
+        if (g) known = unord32(g);
+    }
+    // retire every register load before the loop (see mips_screen_kernel)
+#pragma unroll
+    for (int kb = 0; kb < NKB8; ++kb) asm volatile("" : "+v"(qh[kb]));
+    asm volatile("" : "+v"(qt), "+v"(qa), "+v"(qb), "+v"(known));
+    const f32x2 qt2 = {qt, qt}, qa2 = {qa, qa}, qb2 = {qb, qb};
+    const unsigned sub_row = 4u * (unsigned)(lane >> 4);
+    float lmax = -FLT_MAX;  // largest lower bound this lane has seen
+    int my_cnt = 0;
+    u64* my_list = cand + ((size_t)b * 8 + wave) * kWaveCandCap;
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+
+    for (int it = 0; it < n_it; ++it) {
+        if (it + NS - 2 < n_it) {  // NS - 2 younger stages may stay in flight (the last few iterations simply drain)
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((CPW + (MDR_I8_ABL != 1)) * (NS - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CPW * (NS - 2)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (MODE == 1 && ((it + b) & 31) == 31 && wave_active) {  // exchange lower bounds with the other workgroups (placement: see mips_screen_kernel)
+            float hm = fmaxf(lmax, __shfl_xor(lmax, 16));
+            hm = fmaxf(hm, __shfl_xor(hm, 32));
+            float kn = known;
+            if (lane < 16 && q_valid) {
+                if (hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
+                unsigned g = load_u32_l2(gmax + qlocal);
+                if (g) kn = fmaxf(kn, unord32(g));
+            }
+            known = __shfl(kn, lane & 15);
+        }
+        if (it + NS - 1 < n_it) issue_super_block8<NKB8>(X8, b + (it + NS - 1) * G, lds + ((it + NS - 1) % NS) * SB_BYTES, wave, lane);
+        if (!wave_active || MDR_I8_ABL == 5) continue;
+
+        {
+        const int sb_idx = b + it * G;
+        const char* slot = lds + (it % NS) * SB_BYTES;
+        const char* p = slot + lane * 16;
+        i32x4 a00 = {0, 0, 0, 0}, a01 = a00, a10 = a00, a11 = a00;
+        constexpr int PF = 2;
+        i32x4 x00[PF], x01[PF], x10[PF], x11[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            if (MDR_I8_ABL == 4) { x00[i] = x01[i] = x10[i] = x11[i] = qh[i]; continue; }
+            x00[i] = *(const i32x4*)(p + i * kFragBytes);
+            x01[i] = *(const i32x4*)(p + (HK + i) * kFragBytes);
+            x10[i] = *(const i32x4*)(p + (NKB8 + i) * kFragBytes);
+            x11[i] = *(const i32x4*)(p + (NKB8 + HK + i) * kFragBytes);
+        }
+        // this lane's 8 row scales: rows 4 g .. 4 g + 3 of both 16-row blocks
+        const f32x4 sr0 = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + sub_row * 4);
+        const f32x4 sr1 = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + (16 + sub_row) * 4);
+#pragma unroll
+        for (int kb = 0; kb < HK; ++kb) {
+            const i32x4 c00 = x00[kb % PF], c01 = x01[kb % PF], c10 = x10[kb % PF], c11 = x11[kb % PF];
+            if (kb + PF < HK && MDR_I8_ABL != 4) {
+                x00[kb % PF] = *(const i32x4*)(p + (kb + PF) * kFragBytes);
+                x01[kb % PF] = *(const i32x4*)(p + (HK + kb + PF) * kFragBytes);
+                x10[kb % PF] = *(const i32x4*)(p + (NKB8 + kb + PF) * kFragBytes);
+                x11[kb % PF] = *(const i32x4*)(p + (NKB8 + HK + kb + PF) * kFragBytes);
+            }
+            if (MDR_I8_ABL == 3) { a00 += c00; a01 += c01; a10 += c10; a11 += c11; continue; }
+            a00 = __builtin_amdgcn_mfma_i32_16x16x64_i8(c00, qh[kb], a00, 0, 0, 0);
+            a01 = __builtin_amdgcn_mfma_i32_16x16x64_i8(c01, qh[HK + kb], a01, 0, 0, 0);
+            a10 = __builtin_amdgcn_mfma_i32_16x16x64_i8(c10, qh[kb], a10, 0, 0, 0);
+            a11 = __builtin_amdgcn_mfma_i32_16x16x64_i8(c11, qh[HK + kb], a11, 0, 0, 0);
+        }
+        const i32x4 i0 = a00 + a01, i1 = a10 + a11;
+        if (MDR_I8_ABL == 2) { if (q_valid) lmax = fmaxf(lmax, (float)(i0[0] + i1[0] + i0[1] + i1[1] + i0[2] + i1[2] + i0[3] + i1[3])); continue; }
+        // upper bounds U = s_r (t A + alpha) + beta, two per packed FMA; the lower bound is only needed as a maximum, and
+        // max_r L_r >= L_(argmax U) = max U - 2 (alpha s_(argmax U) + beta) >= max U - 2 (alpha max_r s_r + beta)
+        f32x2 u2[4];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const f32x2 f0 = {(float)i0[2 * pr], (float)i0[2 * pr + 1]}, f1 = {(float)i1[2 * pr], (float)i1[2 * pr + 1]};
+            const f32x2 s0 = {sr0[2 * pr], sr0[2 * pr + 1]}, s1 = {sr1[2 * pr], sr1[2 * pr + 1]};
+            u2[pr] = __builtin_elementwise_fma(__builtin_elementwise_fma(f0, qt2, qa2), s0, qb2);
+            u2[2 + pr] = __builtin_elementwise_fma(__builtin_elementwise_fma(f1, qt2, qa2), s1, qb2);
+        }
+        const float up[8] = {u2[0][0], u2[0][1], u2[1][0], u2[1][1], u2[2][0], u2[2][1], u2[3][0], u2[3][1]};
+        const unsigned row0 = (unsigned)sb_idx * 32u + sub_row;
+        const bool whole = (long long)sb_idx * 32 + 32 <= n_rows;  // wave-uniform
+        const float mu = fmaxf(fmaxf(fmaxf(up[0], up[1]), fmaxf(up[2], up[3])), fmaxf(fmaxf(up[4], up[5]), fmaxf(up[6], up[7])));
+        const float smax = fmaxf(fmaxf(fmaxf(sr0[0], sr0[1]), fmaxf(sr0[2], sr0[3])), fmaxf(fmaxf(sr1[0], sr1[1]), fmaxf(sr1[2], sr1[3])));
+        if (whole && (MODE != 1 || __ballot(q_valid && mu >= known) == 0ull)) {
+            if (q_valid) lmax = fmaxf(lmax, mu - 2.f * fmaf(qa, smax, qb));
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned row = row0 + 16u * h + r;
+                    const bool ok = (long long)row < n_rows && q_valid;
+                    if (ok) lmax = fmaxf(lmax, up[4 * h + r] - 2.f * fmaf(qa, h ? sr1[r] : sr0[r], qb));
+                    if (MODE == 1) {
+                        const bool hit = ok && up[4 * h + r] >= known;
+                        const u64 m = __ballot(hit);
+                        if (m) {  // wave-uniform
+                            const int slot_i = my_cnt + __popcll(m & lt);
+                            if (hit && slot_i < kWaveCandCap) my_list[slot_i] = pack_cand8(q_base + qlocal, up[4 * h + r], row);
+                            my_cnt += __popcll(m);
+                        }
+                    }
+                }
+        }
+        if (MODE == 1) {  // share the maximum between the 4 lanes of a query
+            float hm = fmaxf(lmax, __shfl_xor(lmax, 16));
+            hm = fmaxf(hm, __shfl_xor(hm, 32));
+            known = fmaxf(known, hm);
+        }
+        }
+    }
+    {   // both modes publish: after the main pass gmax holds the largest lower bound over ALL rows, which lets the refinement drop
+        // the candidates that were emitted against an early, loose `known`
+        float hm = fmaxf(lmax, __shfl_xor(lmax, 16));
+        hm = fmaxf(hm, __shfl_xor(hm, 32));
+        if (lane < 16 && q_valid && hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
+    }
+    if (MODE == 1 && lane == 0) {
+        cand_cnt[b * 8 + wave] = my_cnt < kWaveCandCap ? my_cnt : kWaveCandCap;
+        if (my_cnt > kWaveCandCap) *overflow = 1;
+    }
+}
+
+// ---- the int8 tier with 32 queries per wave (256 per pass): v_mfma_i32_32x32x32_i8 ------------------------------------------
+// mips_screen32_kernel's tile on the int8 plane: K-slice s (32 columns) of the 32-row super-block, lane (row = l & 31, k = 32 s +
+// 16 (l >> 5) ..) sits at ((l >> 4) & 1) * NKB8 KiB + (s >> 1) KiB + (s & 1) * 512 + (l >> 5) * 256 + (l & 15) * 16 of the image
+// (the 16x16x64 fragment layout read with the other address pattern, conflict-free); 24 MFMAs per super-block instead of 48,
+// 96 registers of resident query slices instead of 192. Reads and their counted waits are hand-placed as in mfma_chain32.
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+template <int NKB8>
+__device__ __forceinline__ i32x16 mfma_chain8x32(const char* p, const i32x4 (&qf)[2 * NKB8]) {
+    constexpr int NSL = 2 * NKB8, PF = 4;
+    const unsigned a = (unsigned)(uintptr_t)p;
+    i32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0;
+    i32x4 xa[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[i]) : "v"(a), "n"((i >> 1) * kFragBytes + (i & 1) * 512));
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+        const int left = NSL - 1 - sl < PF - 1 ? NSL - 1 - sl : PF - 1;  // reads younger than the one needed now
+        switch (left) {
+            case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xa[sl % PF])); break;
+            case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xa[sl % PF])); break;
+            case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xa[sl % PF])); break;
+            default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[sl % PF])); break;
+        }
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[sl % PF], qf[sl], acc, 0, 0, 0);
+        if (sl + PF < NSL)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[sl % PF]) : "v"(a), "n"(((sl + PF) >> 1) * kFragBytes + ((sl + PF) & 1) * 512));
+    }
+    return acc;
+}
+
+template <int NKB8, int MODE, int NS>
+__global__ void __launch_bounds__(512, 2)
+mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, const char* __restrict__ Q8, const f32x4* __restrict__ qab, int nq, int q_base,
+                     unsigned* __restrict__ gmax, u64* __restrict__ cand, int* __restrict__ cand_cnt, int* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int SB_BYTES = 2 * NKB8 * kFragBytes + kI8Tail;
+    constexpr int CPW = NKB8 / 4;
+    constexpr int NSL = 2 * NKB8;  // 32-deep K slices
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = gridDim.x, b = blockIdx.x;
+    int n_it = (n_sb - b + G - 1) / G;
+    if (MODE == 0 && n_it > kSampleStages) n_it = kSampleStages;
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i)
+        if (i < n_it) issue_super_block8<NKB8>(X8, b + i * G, lds + i * SB_BYTES, wave, lane);
+
+    const bool wave_active = wave * 32 < nq;
+    const int l31 = lane & 31, lh = lane >> 5;
+    i32x4 qf[NSL];
+    {
+        const size_t qrow = (size_t)wave * 32 + l31;
+        const char* qp = Q8 + (qrow >> 4) * ((size_t)NKB8 * kFragBytes) + (qrow & 15) * 16 + lh * 256;
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) qf[sl] = *(const i32x4*)(qp + (sl >> 1) * kFragBytes + (sl & 1) * 512);
+    }
+    const int qlocal = wave * 32 + l31;
+    const bool q_valid = qlocal < nq;
+    f32x4 ab = {0.f, 0.f, 0.f, 0.f};
+    if (q_valid) ab = qab[qlocal];
+    float qt = ab[0], qa = ab[1], qb = ab[2];
+    float known = -FLT_MAX;
+    if (MODE == 1 && q_valid) {
+        unsigned g = gmax[qlocal];
+        if (g) known = unord32(g);
+    }
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) asm volatile("" : "+v"(qf[sl]));
+    asm volatile("" : "+v"(qt), "+v"(qa), "+v"(qb), "+v"(known));
+    const f32x2 qt2 = {qt, qt}, qa2 = {qa, qa}, qb2 = {qb, qb};
+    float lmax = -FLT_MAX;
+    int my_cnt = 0;
+    u64* my_list = cand + ((size_t)b * 8 + wave) * kWaveCandCap;
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int rd_off = ((lane >> 4) & 1) * (NKB8 * kFragBytes) + lh * 256 + (lane & 15) * 16;
+
+    for (int it = 0; it < n_it; ++it) {
+        if (it + NS - 2 < n_it) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((CPW + 1) * (NS - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CPW * (NS - 2)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (MODE == 1 && ((it + b) & 31) == 31 && wave_active) {
+            float hm = fmaxf(lmax, __shfl_xor(lmax, 32));
+            float kn = known;
+            if (lane < 32 && q_valid) {
+                if (hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
+                unsigned g = load_u32_l2(gmax + qlocal);
+                if (g) kn = fmaxf(kn, unord32(g));
+            }
+            known = __shfl(kn, l31);
+        }
+        if (it + NS - 1 < n_it) issue_super_block8<NKB8>(X8, b + (it + NS - 1) * G, lds + ((it + NS - 1) % NS) * SB_BYTES, wave, lane);
+        if (!wave_active) continue;
+
+        const int sb_idx = b + it * G;
+        const char* slot = lds + (it % NS) * SB_BYTES;
+        // this lane's 16 row scales: rows 8 j + 4 lh .. + 3, j = 0..3 (issued first: they are retired with the chain's first wait)
+        f32x4 sr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sr[j] = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + (8 * j + 4 * lh) * 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]));
+        const i32x16 acc = mfma_chain8x32<NKB8>(slot + rd_off, qf);
+        f32x2 u2[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2 f0 = {(float)acc[4 * j], (float)acc[4 * j + 1]}, f1 = {(float)acc[4 * j + 2], (float)acc[4 * j + 3]};
+            const f32x2 s0 = {sr[j][0], sr[j][1]}, s1 = {sr[j][2], sr[j][3]};
+            u2[2 * j] = __builtin_elementwise_fma(__builtin_elementwise_fma(f0, qt2, qa2), s0, qb2);
+            u2[2 * j + 1] = __builtin_elementwise_fma(__builtin_elementwise_fma(f1, qt2, qa2), s1, qb2);
+        }
+        float up[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) up[r] = u2[r >> 1][r & 1];
+        float mu = up[0], smax = sr[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) { mu = fmaxf(mu, up[r]); smax = fmaxf(smax, sr[r >> 2][r & 3]); }
+        const unsigned row0 = (unsigned)sb_idx * 32u + 4u * (unsigned)lh;
+        const bool whole = (long long)sb_idx * 32 + 32 <= n_rows;  // wave-uniform
+        if (whole && (MODE != 1 || __ballot(q_valid && mu >= known) == 0ull)) {
+            if (q_valid) lmax = fmaxf(lmax, mu - 2.f * fmaf(qa, smax, qb));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned row = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
+                const bool ok = (long long)row < n_rows && q_valid;
+                if (ok) lmax = fmaxf(lmax, up[r] - 2.f * fmaf(qa, sr[r >> 2][r & 3], qb));
+                if (MODE == 1) {
+                    const bool hit = ok && up[r] >= known;
+                    const u64 m = __ballot(hit);
+                    if (m) {  // wave-uniform
+                        const int slot_i = my_cnt + __popcll(m & lt);
+                        if (hit && slot_i < kWaveCandCap) my_list[slot_i] = pack_cand8(q_base + qlocal, up[r], row);
+                        my_cnt += __popcll(m);
+                    }
+                }
+            }
+        }
+        if (MODE == 1) known = fmaxf(known, fmaxf(lmax, __shfl_xor(lmax, 32)));  // the two lanes of a query share their bounds
+    }
+    {
+        const float hm = fmaxf(lmax, __shfl_xor(lmax, 32));
+        if (lane < 32 && q_valid && hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
+    }
+    if (MODE == 1 && lane == 0) {
+        cand_cnt[b * 8 + wave] = my_cnt < kWaveCandCap ? my_cnt : kWaveCandCap;
+        if (my_cnt > kWaveCandCap) *overflow = 1;
+    }
+}
+
+// exact re-scoring of the int8 tier's candidates: as mips_refine_kernel, after dropping every candidate whose (rounded-up) upper
+// bound lies below the FINAL largest lower bound of its query -- most of a no-clear-winner query's candidates were emitted early,
+// against a `known` that the pass later raised. ctl8[1] counts the candidates that are really re-scored.
+// How many of the int8 tier's candidates survive that filter (ctl8[2]); one block per list.
+__global__ void __launch_bounds__(256)
+mips_count8_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_cnt, const unsigned* __restrict__ gmax, int* __restrict__ ctl8) {
+    __shared__ int red[4];
+    const int n = cand_cnt[blockIdx.x];
+    if (n == 0) return;
+    const u64* list = cand + (size_t)blockIdx.x * kWaveCandCap;
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const u64 e = list[i];
+        c += ((unsigned)(e >> 32) & 0xFFFFu) >= (gmax[(unsigned)(e >> 48)] >> 16);
+    }
+    c = block_sum_256(c, red);
+    if (threadIdx.x == 0 && c) atomicAdd(ctl8 + 2, c);
+}
+
+// `limit`: survivors beyond which re-scoring them one by one would cost more than the fp16 screen pass behind this tier (data for
+// which the int8 bound is loose: rows with a large common mean, all-ties corpora): the tier then declares itself overflowed.
+__global__ void __launch_bounds__(256)
+mips_refine8_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, const u64* __restrict__ cand,
+                    const int* __restrict__ cand_cnt, const unsigned* __restrict__ gmax, u64* __restrict__ best, int* __restrict__ ctl8, int limit) {
+    if (ctl8[0] || ctl8[2] > limit) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctl8[0] = 1;
+        return;
+    }
+    const int n = cand_cnt[blockIdx.x];
+    if (n == 0) return;
+    const u64* list = cand + (size_t)blockIdx.x * kWaveCandCap;
+    const int sub = threadIdx.x & 15;
+    const int d = nkb * 32;
+    int kept = 0;
+    for (int c = threadIdx.x >> 4; c < n; c += 16) {
+        const u64 e = list[c];
+        const unsigned qi = (unsigned)(e >> 48), u16 = (unsigned)(e >> 32) & 0xFFFFu, row = (unsigned)e;
+        if (u16 < (gmax[qi] >> 16)) continue;  // U < final max L: cannot be the best row
+        const float acc = exact_dot16<false>(Xhi, Xlo, nkb, q + (size_t)qi * d, row, sub);
+        if (sub == 0) { atomicMax(best + qi, make_key(acc, row)); ++kept; }
+    }
+    if (sub == 0 && kept) atomicAdd(ctl8 + 1, kept);
+}
+
 __global__ void fill_empty_kernel(float* D, long long* I, long long n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { D[i] = -FLT_MAX; I[i] = -1; }
@@ -1451,7 +1971,9 @@ struct mdr_index {
     long long cap_rows = 0;  // multiple of 32 (one screen-kernel super-block)
     char* hi = nullptr;      // fragment-tiled planes, cap_rows * d * 2 bytes each
     char* lo = nullptr;
-    int* flags = nullptr;    // device ints: [0] range error seen by add(), [1] same for queries (ignored), [2] max row |x|^2 (float bits)
+    char* i8 = nullptr;      // int8 screening plane (F32X2H storage, d = 768): cap_rows / 32 super-blocks of i8_sb_bytes(d / 64), see mips_screen8_kernel
+    int* flags = nullptr;    // device ints: [0] range error seen by add(), [1] same for queries (ignored), [2] max row |x|^2 (float bits),
+                             // [8], [9] int8 tier: max row scale, max s_r (L1(x8_r)/2 + d/4) (float bits)
     void* stage = nullptr;   // device staging for host-sourced add()
     size_t stage_bytes = 0;
     int variant = 0;
@@ -1463,6 +1985,12 @@ namespace {
 
 size_t plane_bytes_per_row(const mdr_index* h) { return (size_t)h->d * 2; }
 long long pad32(long long n) { return (n + 31) / 32 * 32; }
+
+// the int8 screening plane exists for the storage / dimension the k = 1 screen path serves; MDR_MIPS_I8=0 (read at index creation) leaves it out
+bool wants_i8(const mdr_index* h) {
+    static const bool off = getenv("MDR_MIPS_I8") && atoi(getenv("MDR_MIPS_I8")) == 0;
+    return !off && h->storage != MDR_STORE_BF16 && h->d == 768;
+}
 
 int grow(mdr_index* h, long long need_rows, hipStream_t st) {
     long long need = pad32(need_rows);
@@ -1482,11 +2010,20 @@ int grow(mdr_index* h, long long need_rows, hipStream_t st) {
         if (used) MDR_HIP_TRY(hipMemcpyAsync(planes[i], old[i], used, hipMemcpyDeviceToDevice, st));
         MDR_HIP_TRY(hipMemsetAsync(planes[i] + used, 0, nbytes - used, st));
     }
+    char* n8 = nullptr;
+    if (wants_i8(h)) {
+        const size_t sbb = i8_sb_bytes(h->d / 64), nb8 = (size_t)(ncap / 32) * sbb, used8 = (size_t)(pad32(h->ntotal) / 32) * sbb;
+        MDR_HIP_TRY(hipMalloc((void**)&n8, nb8));
+        if (used8) MDR_HIP_TRY(hipMemcpyAsync(n8, h->i8, used8, hipMemcpyDeviceToDevice, st));
+        MDR_HIP_TRY(hipMemsetAsync(n8 + used8, 0, nb8 - used8, st));
+    }
     MDR_HIP_TRY(hipStreamSynchronize(st));
     for (int i = 0; i < nplanes; ++i)
         if (old[i]) MDR_HIP_TRY(hipFree(old[i]));
+    if (h->i8) MDR_HIP_TRY(hipFree(h->i8));
     h->hi = planes[0];
     h->lo = planes[1];
+    h->i8 = n8;
     h->cap_rows = ncap;
     return MDR_OK;
 }
@@ -1510,6 +2047,8 @@ int launch_add(mdr_index* h, const T* src_dev, long long n, long long row0, hipS
     int rc = launch_convert(h->storage == MDR_STORE_BF16, src_dev, n, n, h->d, row0, h->hi, h->lo, h->flags, st);
     if (rc) return rc;
     hipLaunchKernelGGL(row_norm2_max_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src_dev, n, h->d, h->flags);
+    if (h->i8 && n > 0)
+        hipLaunchKernelGGL(convert_to_i8_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src_dev, n, h->d, row0, h->i8, h->flags + 8);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }
@@ -1543,7 +2082,17 @@ struct SearchPlan {
     int Gg;   // workgroups of the generic kernel (when its lists are needed)
     bool lists_stream, lists_generic;
     size_t off_qhi, off_qlo, off_bound, off_qscale, off_best, off_gmax, off_scand, off_sctl, off_cand, off_cnt, off_kth, total;
+    bool i8;  // the int8 screening tier runs in front of the fp16 screen (k == 1)
+    int G8;   // its workgroups: TWO per CU (24.25 KiB super-blocks: three slots are 73 KiB), one's barrier and epilogue under the other's MFMAs.
+              // Measured at 5 M rows, planted queries, whole call: 1 per CU 1.013 ms, 1 per CU with 64-row stages 0.995 ms, 2 per CU 0.907 ms.
+    size_t off_q8, off_qab, off_ctl8;
 };
+
+#ifndef MDR_I8_SLOTS
+#define MDR_I8_SLOTS 3  // variant-build knob: LDS ring depth of the int8 screen kernels (3: two workgroups per CU, 4-6: one)
+#endif
+// variant 4 = the screen path WITHOUT the int8 tier (tests and A/B runs)
+bool i8_tier(const mdr_index* h, int path, int nq, int k) { return h->i8 != nullptr && h->variant != 4 && path == PATH_SCREEN && k == 1 && nq < 65536; }
 
 SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     SearchPlan p{};
@@ -1575,8 +2124,14 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     p.off_best = take((size_t)(nq > 0 ? nq : 1) * 8);
     p.off_gmax = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
     // k == 1: one private list per wave; k > 1: the [G][kStreamQ] sample maxima
-    p.off_scand = take(p.path != PATH_SCREEN ? 0 : (k == 1 ? (size_t)p.G * 8 * kWaveCandCap * 8 : (size_t)p.G * kWideQ * 4));
-    p.off_sctl = take(p.path == PATH_SCREEN ? 256 + (size_t)p.G * 8 * 4 : 0);            // [0] overflow flag, [64..] per-wave counts
+    p.i8 = i8_tier(h, p.path, nq, k);
+    {
+        const long long per_cu = MDR_I8_SLOTS <= 3 ? 2 : 1;  // workgroups of the int8 kernels per CU (LDS: 3 slots are 73 KiB, 6 are 146 KiB)
+        p.G8 = (int)(units < per_cu * h->num_cus ? (units > 0 ? units : 1) : per_cu * h->num_cus);
+    }
+    const size_t gl = p.i8 && p.G8 > p.G ? (size_t)p.G8 : (size_t)p.G;  // workgroups that own candidate lists
+    p.off_scand = take(p.path != PATH_SCREEN ? 0 : (k == 1 ? gl * 8 * kWaveCandCap * 8 : (size_t)p.G * kWideQ * 4));
+    p.off_sctl = take(p.path == PATH_SCREEN ? 256 + gl * 8 * 4 : 0);            // [0] overflow flag, [64..] per-wave counts
     // the screen-k lists and the lists of its conditional exact pass (which runs after them in stream order) share one region
     size_t lists = p.lists_stream ? (size_t)p.Gx * kStreamQ * kStreamCap : (p.lists_generic ? (size_t)p.Gg * kGenericQ * kGenericCap : 0);
     size_t slots = p.lists_stream ? (size_t)p.Gx * kStreamQ : (p.lists_generic ? (size_t)p.Gg * kGenericQ : 0);
@@ -1589,6 +2144,9 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     p.off_cand = take(lists * 8);
     p.off_cnt = take(slots * 4);
     p.off_kth = take(slots * 8);
+    p.off_q8 = take(p.i8 ? nq_pad * h->d : 0);
+    p.off_qab = take(p.i8 ? nq_pad * 16 : 0);
+    p.off_ctl8 = take(p.i8 ? 256 : 0);  // [0] a candidate list of the int8 tier overflowed -> the fp16 screen runs
     p.total = o + 256;
     return p;
 }
@@ -1615,7 +2173,8 @@ int run_generic(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
 }
 
 template <bool BF>
-int run_screen(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, const char* qhi, u64* best, hipStream_t st) {
+int run_screen(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, const char* qhi, u64* best, hipStream_t st,
+               const int* run_if = nullptr) {
     constexpr int NKB = 24;
     const size_t lds_bytes = 3 * (size_t)NKB * 2 * kFragBytes;
     int rc_ = ensure_dynamic_lds((const void*)mips_screen_kernel<NKB, 0, BF>, (int)lds_bytes);
@@ -1636,19 +2195,49 @@ int run_screen(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, 
         const int nqg = nq - gi * kStreamQ < kStreamQ ? nq - gi * kStreamQ : kStreamQ;
         const char* qg = qhi + gi * qgroup_bytes;
         hipLaunchKernelGGL((mips_screen_kernel<NKB, 0, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
-                           (const float*)(bound + (size_t)gi * kStreamQ), nqg, gi * kStreamQ, gmax + (size_t)gi * kStreamQ, scand, wave_cnt, sctl);
+                           (const float*)(bound + (size_t)gi * kStreamQ), nqg, gi * kStreamQ, gmax + (size_t)gi * kStreamQ, scand, wave_cnt, sctl, run_if);
         hipLaunchKernelGGL((mips_screen_kernel<NKB, 1, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
-                           (const float*)(bound + (size_t)gi * kStreamQ), nqg, gi * kStreamQ, gmax + (size_t)gi * kStreamQ, scand, wave_cnt, sctl);
+                           (const float*)(bound + (size_t)gi * kStreamQ), nqg, gi * kStreamQ, gmax + (size_t)gi * kStreamQ, scand, wave_cnt, sctl, run_if);
         hipLaunchKernelGGL((mips_refine_kernel<BF>), dim3(p.G * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
-                           (const u64*)scand, (const int*)wave_cnt, best);
+                           (const u64*)scand, (const int*)wave_cnt, best, run_if);
         MDR_HIP_TRY(hipGetLastError());
     }
     return MDR_OK;
 }
 
+// k == 1, at most 128 queries, int8 plane present: the int8 tier (sample pass, main pass, exact re-scoring of its candidates)
+int run_screen8(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, u64* best, hipStream_t st) {
+    constexpr int NKB8 = 12, NS = MDR_I8_SLOTS;
+    const size_t lds_bytes = NS * (size_t)(2 * NKB8 * kFragBytes + kI8Tail);
+    int rc_ = ensure_dynamic_lds((const void*)mips_screen8_kernel<NKB8, 0, NS>, (int)lds_bytes);
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen8_kernel<NKB8, 1, NS>, (int)lds_bytes);
+    if (rc_) return rc_;
+    unsigned* gmax = (unsigned*)(ws + p.off_gmax);
+    u64* scand = (u64*)(ws + p.off_scand);
+    int* wave_cnt = (int*)(ws + p.off_sctl) + 64;
+    int* ctl8 = (int*)(ws + p.off_ctl8);
+    char* q8 = ws + p.off_q8;
+    f32x4* qab = (f32x4*)(ws + p.off_qab);
+    const int nq_pad = kStreamQ;
+    const int n_sb = (int)((h->ntotal + 31) / 32);
+    MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
+    MDR_HIP_TRY(hipMemsetAsync(ctl8, 0, 256, st));
+    hipLaunchKernelGGL(prep_queries_i8_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)(h->flags + 8), q8, qab);
+    hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 0, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
+                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8);
+    hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 1, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
+                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8);
+    hipLaunchKernelGGL(mips_count8_kernel, dim3(p.G8 * 8), dim3(256), 0, st, (const u64*)scand, (const int*)wave_cnt, (const unsigned*)gmax, ctl8);
+    hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8 * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
+                       (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nq);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
 // k == 1, more than 128 queries: the same three launches per group of 256 queries on the 32-queries-per-wave kernel
 template <bool BF>
-int run_screen32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, const char* qhi, u64* best, hipStream_t st) {
+int run_screen32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, const char* qhi, u64* best, hipStream_t st,
+                 const int* run_if = nullptr) {
     constexpr int NKB = 24;
     const size_t lds_bytes = 3 * (size_t)NKB * 2 * kFragBytes;
     int rc_ = ensure_dynamic_lds((const void*)mips_screen32_kernel<NKB, 0, BF>, (int)lds_bytes);
@@ -1669,11 +2258,46 @@ int run_screen32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
         const int nqg = nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ;
         const char* qg = qhi + gi * qgroup_bytes;
         hipLaunchKernelGGL((mips_screen32_kernel<NKB, 0, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
-                           (const float*)(bound + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, sctl);
+                           (const float*)(bound + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, sctl, run_if);
         hipLaunchKernelGGL((mips_screen32_kernel<NKB, 1, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
-                           (const float*)(bound + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, sctl);
+                           (const float*)(bound + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, sctl, run_if);
         hipLaunchKernelGGL((mips_refine_kernel<BF>), dim3(p.G * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
-                           (const u64*)scand, (const int*)wave_cnt, best);
+                           (const u64*)scand, (const int*)wave_cnt, best, run_if);
+        MDR_HIP_TRY(hipGetLastError());
+    }
+    return MDR_OK;
+}
+
+// k == 1, more than 128 queries, int8 plane present: the int8 tier per group of 256 queries
+int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, u64* best, hipStream_t st) {
+    constexpr int NKB8 = 12, NS = MDR_I8_SLOTS;
+    const size_t lds_bytes = NS * (size_t)(2 * NKB8 * kFragBytes + kI8Tail);
+    int rc_ = ensure_dynamic_lds((const void*)mips_screen8w_kernel<NKB8, 0, NS>, (int)lds_bytes);
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen8w_kernel<NKB8, 1, NS>, (int)lds_bytes);
+    if (rc_) return rc_;
+    unsigned* gmax = (unsigned*)(ws + p.off_gmax);
+    u64* scand = (u64*)(ws + p.off_scand);
+    int* wave_cnt = (int*)(ws + p.off_sctl) + 64;
+    int* ctl8 = (int*)(ws + p.off_ctl8);
+    char* q8 = ws + p.off_q8;
+    f32x4* qab = (f32x4*)(ws + p.off_qab);
+    const int ngroups = (nq + kWideQ - 1) / kWideQ;
+    const int nq_pad = ngroups * kWideQ;
+    const int n_sb = (int)((h->ntotal + 31) / 32);
+    MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
+    MDR_HIP_TRY(hipMemsetAsync(ctl8, 0, 256, st));
+    hipLaunchKernelGGL(prep_queries_i8_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)(h->flags + 8), q8, qab);
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int nqg = nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ;
+        const char* qg = q8 + (size_t)gi * kWideQ * h->d;
+        hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 0, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
+                           (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8);
+        hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 1, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
+                           (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8);
+        MDR_HIP_TRY(hipMemsetAsync(ctl8 + 2, 0, sizeof(int), st));
+        hipLaunchKernelGGL(mips_count8_kernel, dim3(p.G8 * 8), dim3(256), 0, st, (const u64*)scand, (const int*)wave_cnt, (const unsigned*)gmax, ctl8);
+        hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8 * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
+                           (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nqg);
         MDR_HIP_TRY(hipGetLastError());
     }
     return MDR_OK;
@@ -1795,6 +2419,7 @@ int mdr_index_free(mdr_index* h) {
     DeviceGuard g(h->device);
     if (h->hi) (void)hipFree(h->hi);
     if (h->lo) (void)hipFree(h->lo);
+    if (h->i8) (void)hipFree(h->i8);
     if (h->flags) (void)hipFree(h->flags);
     if (h->stage) (void)hipFree(h->stage);
     delete h;
@@ -1865,7 +2490,7 @@ int64_t mdr_index_stream_bytes(const mdr_index* h) { return h ? (int64_t)((h->nt
 
 int mdr_index_set_variant(mdr_index* h, int variant) {
     MDR_REQUIRE(h != nullptr, "index handle is NULL");
-    MDR_REQUIRE(variant >= 0 && variant <= 3, "variant must be 0 (auto), 1 (generic), 2 (exact stream) or 3 (screen + refine)");
+    MDR_REQUIRE(variant >= 0 && variant <= 4, "variant must be 0 (auto), 1 (generic), 2 (exact stream), 3 (screen + refine) or 4 (screen + refine without the int8 tier)");
     h->variant = variant;
     return MDR_OK;
 }
@@ -1945,9 +2570,17 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
         MDR_HIP_TRY(hipMemsetAsync(best, 0, (size_t)nq * 8, st));
         const int* run_if = nullptr;
         if (p.path == PATH_SCREEN) {
-            if (wide_pass(nq)) {  // more than 128 queries: 256 per corpus pass on the 32-queries-per-wave kernel
+            if (wide_pass(nq) && p.i8) {  // int8 tier, 256 queries per pass; the fp16 wide screen only behind an overflow
+                rc = run_screen8w(h, p, ws, q_dev, nq, best, st);
+                if (!rc) rc = run_screen32<false>(h, p, ws, q_dev, nq, qhi, best, st, (const int*)(ws + p.off_ctl8));
+                h->last_kernel = "mips_screen8w_kernel<12,1>";
+            } else if (wide_pass(nq)) {  // more than 128 queries: 256 per corpus pass on the 32-queries-per-wave kernel
                 rc = bf ? run_screen32<true>(h, p, ws, q_dev, nq, qhi, best, st) : run_screen32<false>(h, p, ws, q_dev, nq, qhi, best, st);
                 h->last_kernel = bf ? "mips_screen32_kernel<24,1,bf16>" : "mips_screen32_kernel<24,1>";
+            } else if (p.i8) {  // int8 tier first; the fp16 screen only if one of its lists overflowed, the exact pass only if that one's did
+                rc = run_screen8(h, p, ws, q_dev, nq, best, st);
+                if (!rc) rc = run_screen<false>(h, p, ws, q_dev, nq, qhi, best, st, (const int*)(ws + p.off_ctl8));
+                h->last_kernel = "mips_screen8_kernel<12,1>";
             } else {
                 rc = bf ? run_screen<true>(h, p, ws, q_dev, nq, qhi, best, st) : run_screen<false>(h, p, ws, q_dev, nq, qhi, best, st);
                 h->last_kernel = bf ? "mips_screen_kernel<24,1,bf16>" : "mips_screen_kernel<24,1>";
@@ -2036,7 +2669,7 @@ int mdr_index_search_telemetry(const mdr_index* h, int nq, int k, const void* wo
     MDR_HIP_TRY(hipMemcpyAsync(&overflow, ws + p.off_sctl, sizeof(int), hipMemcpyDeviceToHost, st));
     long long total = 0;
     if (k == 1) {  // per-wave list lengths of the last query group
-        const size_t n_cnt = (size_t)p.G * 8;
+        const size_t n_cnt = (size_t)(p.i8 && p.G8 > p.G ? p.G8 : p.G) * 8;
         int* cnt = new (std::nothrow) int[n_cnt];
         MDR_REQUIRE(cnt != nullptr, "out of host memory");
         hipError_t e = hipMemcpyAsync(cnt, ws + p.off_sctl + 256, n_cnt * sizeof(int), hipMemcpyDeviceToHost, st);
@@ -2052,6 +2685,15 @@ int mdr_index_search_telemetry(const mdr_index* h, int nq, int k, const void* wo
     }
     out4_host[0] = overflow;
     out4_host[1] = total;
+    if (p.i8) {  // bit 9: the int8 tier ran in front; bit 8: one of its lists overflowed (the fp16 screen ran behind it)
+        int o8 = 0;
+        MDR_HIP_TRY(hipMemcpyAsync(&o8, ws + p.off_ctl8, sizeof(int), hipMemcpyDeviceToHost, st));
+        MDR_HIP_TRY(hipStreamSynchronize(st));
+        int kept = 0;
+        MDR_HIP_TRY(hipMemcpyAsync(&kept, ws + p.off_ctl8 + sizeof(int), sizeof(int), hipMemcpyDeviceToHost, st));
+        MDR_HIP_TRY(hipStreamSynchronize(st));
+        out4_host[3] |= 512 | (o8 ? 256 : 0) | ((int64_t)kept << 16);  // bits 16..: candidates of the int8 tier that were really re-scored
+    }
     return MDR_OK;
 }
 

@@ -1,0 +1,32 @@
+import os, sys, torch, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multihop_dense_retrieval_amd import index as mi
+dev = torch.device("cuda", 0)
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+idx = mi.IndexFlatIP(768, device=dev)
+idx.reserve(rows)
+g = torch.Generator(device=dev).manual_seed(0)
+chunks = []
+for lo in range(0, rows, 250_000):
+    x = torch.randn((min(250_000, rows - lo), 768), generator=g, device=dev)
+    idx.add(x)
+    if lo < 1_000_000: chunks.append(x)
+X = torch.cat(chunks)
+NQ = int(os.environ.get("I8_NQ", "100"))
+for name, q in (("random", torch.randn((NQ, 768), generator=g, device=dev)), ("planted", X[:NQ] + 0.05 * torch.randn((NQ, 768), generator=g, device=dev))):
+    res = {}
+    for v in (3, 4, 2):
+        idx.set_variant(v)
+        D, I = idx.search_device(q, 1)
+        torch.cuda.synchronize()
+        t = idx.telemetry(NQ, 1)
+        for _ in range(2): idx.search_device(q, 1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): idx.search_device(q, 1)
+        e1.record(); torch.cuda.synchronize()
+        res[v] = (D.clone(), I.clone())
+        print(f"{name} rows {rows} variant {v} {idx.last_kernel():30s} {e0.elapsed_time(e1)/10:7.3f} ms  telemetry {t}", flush=True)
+    for v in (3, 4):
+        same_i = bool((res[v][1] == res[2][1]).all()); dmax = float((res[v][0] - res[2][0]).abs().max())
+        print(f"   variant {v} vs exact: ids equal {same_i}  max |dD| {dmax:.3e}")

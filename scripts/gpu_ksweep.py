@@ -12,15 +12,16 @@ from multihop_dense_retrieval_amd import index as mdr_index  # noqa: E402
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 storage = sys.argv[2] if len(sys.argv) > 2 else "f32x2h"
 dev = torch.device("cuda", 0)
-idx = mdr_index.IndexFlatIP(768, device=dev, storage=storage) if storage == "bf16" else mdr_index.IndexFlatIP(768, device=dev)
+DIM = int(os.environ.get("SWEEP_DIM", "768"))
+idx = mdr_index.IndexFlatIP(DIM, device=dev, storage=storage) if storage == "bf16" else mdr_index.IndexFlatIP(DIM, device=dev)
 idx.reserve(rows)
 g = torch.Generator(device=dev).manual_seed(0)
 for lo in range(0, rows, 250_000):
-    idx.add(torch.randn((min(250_000, rows - lo), 768), generator=g, device=dev))
+    idx.add(torch.randn((min(250_000, rows - lo), DIM), generator=g, device=dev))
 planted_mode = os.environ.get("SWEEP_PLANTED") == "1"
-probe = torch.randn((800, 768), generator=torch.Generator(device=dev).manual_seed(0), device=dev)  # == rows 0..799 of the corpus
+probe = torch.randn((800, DIM), generator=torch.Generator(device=dev).manual_seed(0), device=dev)  # == rows 0..799 of the corpus
 for nq in (100, 800) if not os.environ.get("SWEEP_NQ") else (int(os.environ["SWEEP_NQ"]),):
-    q = torch.randn((nq, 768), generator=g, device=dev)
+    q = torch.randn((nq, DIM), generator=g, device=dev)
     if planted_mode:  # bench-like queries: a corpus row plus 5% noise (one clear winner per query)
         q = probe[:nq] + 0.05 * q
     for k in (1, 4, 8, 100) if not os.environ.get("SWEEP_K") else (int(os.environ["SWEEP_K"]),):

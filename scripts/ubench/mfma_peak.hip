@@ -7,6 +7,8 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 template <int SHAPE, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) peak(const half8* __restrict__ in, float* __restrict__ out, int iters) {
@@ -21,6 +23,22 @@ __global__ void __launch_bounds__(64 * WAVES) peak(const half8* __restrict__ in,
             for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i & 3], b[i >> 2], acc[i], 0, 0, 0);
         }
         for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else if (SHAPE == 816) {  // v_mfma_i32_16x16x64_i8
+        i32x4 acc[16];
+        for (int i = 0; i < 16; ++i) acc[i] = (i32x4){0, 0, 0, 0};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a[i & 3]), __builtin_bit_cast(i32x4, b[i >> 2]), acc[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 16; ++i) s += (float)(acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3]);
+    } else if (SHAPE == 832) {  // v_mfma_i32_32x32x32_i8
+        i32x16 acc[8];
+        for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a[i & 3]), __builtin_bit_cast(i32x4, b[i >> 2]), acc[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) s += (float)acc[i][j];
     } else {
         f32x16 acc[8];
         for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
@@ -45,8 +63,8 @@ void run(const half8* in, float* out, int blocks, const char* name) {
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double flop = 5.0 * blocks * WAVES * iters * (SHAPE == 16 ? 16 * 16384.0 : 8 * 32768.0);
-    const double mf = 5.0 * blocks * WAVES * iters * (SHAPE == 16 ? 16 : 8);
+    const double flop = 5.0 * blocks * WAVES * iters * (SHAPE == 16 ? 16 * 16384.0 : SHAPE == 816 ? 16 * 32768.0 : SHAPE == 832 ? 8 * 65536.0 : 8 * 32768.0);
+    const double mf = 5.0 * blocks * WAVES * iters * (SHAPE == 16 || SHAPE == 816 ? 16 : 8);
     printf("%-28s %d waves/CU: %8.1f TFLOP/s  (%.2f ms)  = %.1f ns per MFMA per SIMD\n", name, WAVES, flop / ms / 1e9, ms / 5, ms * 1e6 / (mf / (blocks * 4)));
 }
 
@@ -65,5 +83,9 @@ int main(int argc, char** argv) {
     run<32, 8>(in, out, 256, "32x32x16 f16");
     run<16, 4>(in, out, 256, "16x16x32 f16");
     run<32, 4>(in, out, 256, "32x32x16 f16");
+    run<816, 8>(in, out, 256, "16x16x64 i8 (ops)");
+    run<832, 8>(in, out, 256, "32x32x32 i8 (ops)");
+    run<816, 4>(in, out, 256, "16x16x64 i8 (ops)");
+    run<832, 4>(in, out, 256, "32x32x32 i8 (ops)");
     return 0;
 }
