@@ -16,8 +16,9 @@ N > 1   : launched by torch.distributed.run, one rank per GPU. The 5M-row corpus
           10 ms step of 2 x 12 dependent transformer layers is latency-bound there.
 Prints ONE JSON line on rank 0 with
   roofline          the MIPS kernel (HBM-bound): PHYSICAL HBM bytes per search call / HIP-event time of the call on the launch
-                    stream / 8 TB/s. The screen kernels stream only the fp16 hi plane of the fp32-accurate index, so the
-                    fp32-equivalent ("algorithmic", SURVEY.md §8d: N x d x 4 bytes) rate is a SEPARATE key, never `frac`.
+                    stream / 8 TB/s. The screen kernels stream only the int8 screening plane (beam = 1: 776 B per row) or the
+                    fp16 hi plane of the fp32-accurate index, so the fp32-equivalent ("algorithmic", SURVEY.md §8d:
+                    N x d x 4 bytes) rate is a SEPARATE key, never `frac`.
   roofline_encoder  the encoder (MFMA-bound, the larger share of the step): executed FLOPs / stage time / 2.5 PFLOP/s.
   self_check        structural properties + `full_size_exact`: after the timed region every row of the 5M corpus is
                     re-scored with a plain torch matmul and compared with what the kernels returned.
@@ -52,6 +53,10 @@ PMC_TRAFFIC_RATIO = {
     # 32 queries per wave: main 3.75258e6 KB + refine 52561 KB + sample 26145 KB, x2 -> 7.847e9 B per search (200 queries)
     "mips_screen32_kernel": (0.5109, "profiles/r02_mips5m_pmc_pipelined_FETCH_SIZE.csv"),
     "mips_stream_kernel": (1.001, "profiles/r01_mips1m_pmc_fetch_size.csv"),
+    # int8 screening tier (776 B per row), 16 queries per wave: main 1.89632e6 KB + sample 25252 + refine 2194 + count 838, x2 -> 3.942e9 B per search
+    "mips_screen8_kernel": (0.2566, "profiles/r02_mips5m_i8_pmc_sequential_FETCH_SIZE.csv"),
+    # 32 queries per wave: main 1.89725e6 KB + sample 25648 + refine 3473 + count 1034, x2 -> 3.947e9 B per search (200 queries)
+    "mips_screen8w_kernel": (0.2570, "profiles/r02_mips5m_i8_pmc_pipelined_FETCH_SIZE.csv"),
 }
 
 
@@ -222,7 +227,7 @@ def mips_roofline(pipe, local, args, d):
             "queries_per_launch": round(float(np.mean([nq for _, nq in calls])), 1) if calls else 0,
             "corpus_passes_per_launch": round(float(np.mean(passes)), 3) if passes else 0, "queries_per_pass": qpp,
             "note": "achieved/frac = physical HBM bytes (rocprofv3 FETCH_SIZE, gfx950-corrected) / HIP-event time of the whole search call; "
-                    "the screen kernels stream only the fp16 hi plane, so the fp32-equivalent (algorithmic) rate is reported separately. "
+                    "the screen kernels stream only the int8 plane (beam = 1; 776 B per row) or the fp16 hi plane, so the fp32-equivalent (algorithmic) rate is reported separately. "
                     "Pipelined loop: one 256-query pass serves hop 2 of a batch and hop 1 of the next (MFMA-heavier, lower HBM fraction, half "
                     "the passes); `sequential.mips_roofline` is the beam=1, 100-queries-per-call kernel the north star's HBM target names"}
 

@@ -1,7 +1,8 @@
 #!/bin/bash
 # HBM traffic (FETCH_SIZE / WRITE_SIZE) and SQ counters of the MIPS screen kernels at 5M rows -> gpurun_out/<tag>/
-#   sequential loop: mips_screen_kernel   (16 queries per wave, nq = 100 per call)
-#   pipelined loop : mips_screen32_kernel (32 queries per wave, nq = 200 per call)
+#   sequential loop: mips_screen8_kernel  / mips_screen_kernel   (16 queries per wave, nq = 100 per call; int8 tier / fp16 screen)
+#   pipelined loop : mips_screen8w_kernel / mips_screen32_kernel (32 queries per wave, nq = 200 per call)
+# (fp16 screen alone: MDR_MIPS_I8=0 in the environment)
 # Counters are collected in their own passes with --kernel-trace only (no other trace domain).
 set -u
 TAG=${1:-pmcs}; REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
@@ -12,7 +13,7 @@ for MODE in sequential pipelined; do
     N=$(echo $PMC | tr ' ' '_' | cut -c1-30)
     timeout 300 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/p -o p -- python $REPO/bench.py --rows 5000000 --steps 3 --warmup 1 --no-encoder --no-cpu-baseline --no-sequential --no-verify $FLAG > $OUT/log_${MODE}_$N.txt 2>&1
     P=$(find $OUT/p -name "*counter_collection.csv" | head -1)
-    if [ -n "$P" ]; then head -1 "$P" > $OUT/${MODE}_$N.csv; grep -E "mips_(screen|screen32|refine)" "$P" >> $OUT/${MODE}_$N.csv; fi
+    if [ -n "$P" ]; then head -1 "$P" > $OUT/${MODE}_$N.csv; grep -E "mips_(screen|screen32|screen8|screen8w|refine|refine8|count8)" "$P" >> $OUT/${MODE}_$N.csv; fi
     rm -rf $OUT/p
   done
 done
@@ -22,8 +23,9 @@ for f in sorted(glob.glob(sys.argv[1] + "/*_*.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        kern = "screen32" if "screen32" in n else "screen" if "mips_screen_kernel" in n else "refine"
-        mode = "main" if "<24, 1" in n else "sample" if "<24, 0" in n else ""
+        kern = ("screen8w" if "screen8w" in n else "screen8" if "screen8_kernel" in n else "screen32" if "screen32" in n
+                else "screen" if "mips_screen_kernel" in n else "count8" if "count8" in n else "refine8" if "refine8" in n else "refine")
+        mode = "main" if ("<24, 1" in n or "<12, 1" in n) else "sample" if ("<24, 0" in n or "<12, 0" in n) else ""
         dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         agg[(kern + " " + mode, r["Counter_Name"])].append((float(r["Counter_Value"]), dur))
     for (k, c), v in sorted(agg.items()):
