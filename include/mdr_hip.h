@@ -192,6 +192,9 @@ int mdr_test_gemm_f16(const void* A_dev, const void* W_dev, const float* bias_de
  * knob MDR_GEMM_ABL=5 (shader cycles of wave 0 summed over workgroups: [0] wait + barrier A, [1..3] sub-phases 1-3,
  * [4] wait + barrier B, [5] sub-phase 4, [6] epilogue, [7] K-tiles counted); synchronises the device; reset != 0 clears it. */
 int mdr_test_gemm_stamps(unsigned long long* out8_host, int reset);
+/* Measurement hook: the same kind of timeline for the 32-queries-per-wave int8 screen kernel, filled only by a library built with
+ * -DMDR_I8_ABL=9 ([0] wait + barrier, [1] exchange + DMA issue, [2] MFMA chain, [3] epilogue, [4] bound sharing, [7] stages). */
+int mdr_test_i8_stamps(unsigned long long* out8_host, int reset);
 
 #ifdef __cplusplus
 }

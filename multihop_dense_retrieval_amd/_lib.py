@@ -63,6 +63,7 @@ _SIGNATURES = {
     "mdr_test_gemm_f16": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int,
                                      _c.c_int, _c.c_int, _c.c_void_p]),
     "mdr_test_gemm_stamps": (_c.c_int, [_c.POINTER(_c.c_uint64), _c.c_int]),
+    "mdr_test_i8_stamps": (_c.c_int, [_c.POINTER(_c.c_uint64), _c.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1644,6 +1644,10 @@ __device__ __forceinline__ i32x16 mfma_chain8x32(const char* p, const i32x4 (&qf
     return acc;
 }
 
+// MDR_I8_ABL=9 builds: s_memtime timeline of wave 0 of every workgroup of the MODE 1 wide kernel, summed:
+// [0] wait + barrier, [1] exchange + DMA issue, [2] scale reads + MFMA chain, [3] epilogue (incl. bound sharing), [7] stages
+__device__ unsigned long long g_i8_stamp[8];
+
 template <int NKB8, int MODE, int NS>
 __global__ void __launch_bounds__(512, 2)
 mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, const char* __restrict__ Q8, const f32x4* __restrict__ qab, int nq, int q_base,
@@ -1691,36 +1695,7 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
     const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const int rd_off = ((lane >> 4) & 1) * (NKB8 * kFragBytes) + lh * 256 + (lane & 15) * 16;
 
-    for (int it = 0; it < n_it; ++it) {
-        if (it + NS - 2 < n_it) {
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((CPW + 1) * (NS - 2)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CPW * (NS - 2)) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (MODE == 1 && ((it + b) & 31) == 31 && wave_active) {
-            float hm = fmaxf(lmax, __shfl_xor(lmax, 32));
-            float kn = known;
-            if (lane < 32 && q_valid) {
-                if (hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
-                unsigned g = load_u32_l2(gmax + qlocal);
-                if (g) kn = fmaxf(kn, unord32(g));
-            }
-            known = __shfl(kn, l31);
-        }
-        if (it + NS - 1 < n_it) issue_super_block8<NKB8>(X8, b + (it + NS - 1) * G, lds + ((it + NS - 1) % NS) * SB_BYTES, wave, lane);
-        if (!wave_active) continue;
-
-        const int sb_idx = b + it * G;
-        const char* slot = lds + (it % NS) * SB_BYTES;
-        // this lane's 16 row scales: rows 8 j + 4 lh .. + 3, j = 0..3 (issued first: they are retired with the chain's first wait)
-        f32x4 sr[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sr[j] = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + (8 * j + 4 * lh) * 4);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]));
-        const i32x16 acc = mfma_chain8x32<NKB8>(slot + rd_off, qf);
+    auto epilogue = [&](const i32x16& acc, const f32x4 (&sr)[4], int sb_idx) __attribute__((always_inline)) {
         f32x2 u2[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1757,6 +1732,57 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
             }
         }
         if (MODE == 1) known = fmaxf(known, fmaxf(lmax, __shfl_xor(lmax, 32)));  // the two lanes of a query share their bounds
+    };
+    unsigned long long st_sum[5] = {0, 0, 0, 0, 0}, st_t = 0;
+    auto stamp = [&](int seg) __attribute__((always_inline)) {
+        if (MDR_I8_ABL != 9 || MODE != 1) return;
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (seg >= 0) st_sum[seg] += now - st_t;
+        st_t = now;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    stamp(-1);
+    for (int it = 0; it < n_it; ++it) {
+        if (it + NS - 2 < n_it) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((CPW + 1) * (NS - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CPW * (NS - 2)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp(0);
+        if (MODE == 1 && ((it + b) & 31) == 31 && wave_active) {
+            float hm = fmaxf(lmax, __shfl_xor(lmax, 32));
+            float kn = known;
+            if (lane < 32 && q_valid) {
+                if (hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
+                unsigned g = load_u32_l2(gmax + qlocal);
+                if (g) kn = fmaxf(kn, unord32(g));
+            }
+            known = __shfl(kn, l31);
+        }
+        if (it + NS - 1 < n_it) issue_super_block8<NKB8>(X8, b + (it + NS - 1) * G, lds + ((it + NS - 1) % NS) * SB_BYTES, wave, lane);
+        stamp(1);
+        if (!wave_active) continue;
+
+        const int sb_idx = b + it * G;
+        const char* slot = lds + (it % NS) * SB_BYTES;
+        // this lane's 16 row scales: rows 8 j + 4 lh .. + 3, j = 0..3
+        f32x4 sr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sr[j] = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + (8 * j + 4 * lh) * 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]));
+        const i32x16 acc = mfma_chain8x32<NKB8>(slot + rd_off, qf);
+        stamp(2);
+        epilogue(acc, sr, sb_idx);
+        stamp(3);
+    }
+    if (MDR_I8_ABL == 9 && MODE == 1 && threadIdx.x == 0) {
+#pragma unroll
+        for (int e = 0; e < 5; ++e) atomicAdd(&g_i8_stamp[e], st_sum[e]);
+        atomicAdd(&g_i8_stamp[7], (unsigned long long)n_it);
     }
     {
         const float hm = fmaxf(lmax, __shfl_xor(lmax, 32));
@@ -2083,11 +2109,15 @@ struct SearchPlan {
     bool lists_stream, lists_generic;
     size_t off_qhi, off_qlo, off_bound, off_qscale, off_best, off_gmax, off_scand, off_sctl, off_cand, off_cnt, off_kth, total;
     bool i8;  // the int8 screening tier runs in front of the fp16 screen (k == 1)
+    int G8w;  // workgroups of its 32-queries-per-wave kernel
     int G8;   // its workgroups: TWO per CU (24.25 KiB super-blocks: three slots are 73 KiB), one's barrier and epilogue under the other's MFMAs.
               // Measured at 5 M rows, planted queries, whole call: 1 per CU 1.013 ms, 1 per CU with 64-row stages 0.995 ms, 2 per CU 0.907 ms.
     size_t off_q8, off_qab, off_ctl8;
 };
 
+#ifndef MDR_I8W_SLOTS
+#define MDR_I8W_SLOTS 6  // the 32-queries-per-wave int8 kernel needs 178 VGPRs: ONE workgroup per CU, so its ring is deep instead (5 stages = 121 KiB in flight)
+#endif
 #ifndef MDR_I8_SLOTS
 #define MDR_I8_SLOTS 3  // variant-build knob: LDS ring depth of the int8 screen kernels (3: two workgroups per CU, 4-6: one)
 #endif
@@ -2128,6 +2158,7 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     {
         const long long per_cu = MDR_I8_SLOTS <= 3 ? 2 : 1;  // workgroups of the int8 kernels per CU (LDS: 3 slots are 73 KiB, 6 are 146 KiB)
         p.G8 = (int)(units < per_cu * h->num_cus ? (units > 0 ? units : 1) : per_cu * h->num_cus);
+        p.G8w = p.G;  // the 32-queries-per-wave kernel: one per CU
     }
     const size_t gl = p.i8 && p.G8 > p.G ? (size_t)p.G8 : (size_t)p.G;  // workgroups that own candidate lists
     p.off_scand = take(p.path != PATH_SCREEN ? 0 : (k == 1 ? gl * 8 * kWaveCandCap * 8 : (size_t)p.G * kWideQ * 4));
@@ -2270,7 +2301,7 @@ int run_screen32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
 
 // k == 1, more than 128 queries, int8 plane present: the int8 tier per group of 256 queries
 int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, u64* best, hipStream_t st) {
-    constexpr int NKB8 = 12, NS = MDR_I8_SLOTS;
+    constexpr int NKB8 = 12, NS = MDR_I8W_SLOTS;
     const size_t lds_bytes = NS * (size_t)(2 * NKB8 * kFragBytes + kI8Tail);
     int rc_ = ensure_dynamic_lds((const void*)mips_screen8w_kernel<NKB8, 0, NS>, (int)lds_bytes);
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen8w_kernel<NKB8, 1, NS>, (int)lds_bytes);
@@ -2290,13 +2321,13 @@ int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
     for (int gi = 0; gi < ngroups; ++gi) {
         const int nqg = nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ;
         const char* qg = q8 + (size_t)gi * kWideQ * h->d;
-        hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 0, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
+        hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 0, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
                            (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8);
-        hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 1, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
+        hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 1, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
                            (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8);
         MDR_HIP_TRY(hipMemsetAsync(ctl8 + 2, 0, sizeof(int), st));
-        hipLaunchKernelGGL(mips_count8_kernel, dim3(p.G8 * 8), dim3(256), 0, st, (const u64*)scand, (const int*)wave_cnt, (const unsigned*)gmax, ctl8);
-        hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8 * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
+        hipLaunchKernelGGL(mips_count8_kernel, dim3(p.G8w * 8), dim3(256), 0, st, (const u64*)scand, (const int*)wave_cnt, (const unsigned*)gmax, ctl8);
+        hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8w * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
                            (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nqg);
         MDR_HIP_TRY(hipGetLastError());
     }
@@ -2651,6 +2682,17 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
     return MDR_OK;
 }
 
+int mdr_test_i8_stamps(unsigned long long* out8_host, int reset) {
+    MDR_REQUIRE(out8_host, "NULL pointer");
+    MDR_HIP_TRY(hipDeviceSynchronize());
+    MDR_HIP_TRY(hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_i8_stamp), 8 * sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        MDR_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_i8_stamp), z, sizeof(z)));
+    }
+    return MDR_OK;
+}
+
 int mdr_index_search_telemetry(const mdr_index* h, int nq, int k, const void* workspace_dev, int64_t* out4_host, void* stream) {
     MDR_REQUIRE(h && workspace_dev && out4_host, "NULL argument");
     MDR_REQUIRE(nq >= 1 && k >= 1 && k <= kKMax, "bad shape");
@@ -2669,7 +2711,7 @@ int mdr_index_search_telemetry(const mdr_index* h, int nq, int k, const void* wo
     MDR_HIP_TRY(hipMemcpyAsync(&overflow, ws + p.off_sctl, sizeof(int), hipMemcpyDeviceToHost, st));
     long long total = 0;
     if (k == 1) {  // per-wave list lengths of the last query group
-        const size_t n_cnt = (size_t)(p.i8 && p.G8 > p.G ? p.G8 : p.G) * 8;
+        const size_t n_cnt = (size_t)(p.i8 ? (wide_pass(nq) ? p.G8w : p.G8) : p.G) * 8;
         int* cnt = new (std::nothrow) int[n_cnt];
         MDR_REQUIRE(cnt != nullptr, "out of host memory");
         hipError_t e = hipMemcpyAsync(cnt, ws + p.off_sctl + 256, n_cnt * sizeof(int), hipMemcpyDeviceToHost, st);

@@ -30,3 +30,11 @@ for name, q in (("random", torch.randn((NQ, 768), generator=g, device=dev)), ("p
     for v in (3, 4):
         same_i = bool((res[v][1] == res[2][1]).all()); dmax = float((res[v][0] - res[2][0]).abs().max())
         print(f"   variant {v} vs exact: ids equal {same_i}  max |dD| {dmax:.3e}")
+
+if os.environ.get("I8_STAMPS"):
+    import ctypes
+    from multihop_dense_retrieval_amd import _lib
+    buf = (ctypes.c_uint64 * 8)()
+    _lib.check(_lib.lib().mdr_test_i8_stamps(buf, 1))
+    n = max(1, buf[7])
+    print("int8 wide kernel, cycles per stage (wave 0): " + "  ".join(f"{nm} {buf[i] / n:7.1f}" for i, nm in enumerate(("wait+barrier", "exch+dma", "chain", "epilogue", "share"))) + f"  total {sum(buf[:5]) / n:7.1f}")
