@@ -185,3 +185,37 @@ def test_corpus_store_round_trips_the_corpus_dict(tmp_path):
     assert {v["title"]: v["text"] for v in st2.values()} == {f"t{i}": f"x{i}" for i in range(5)}
     with pytest.raises(ValueError):
         corpus_store.build_store({"0": ["a", "b"], "2": ["c", "d"]}, str(tmp_path / "bad.store"))
+
+
+def test_int8_screen_bound_is_rigorous():
+    """The inequality the int8 screening tier of csrc/mdr_mips.hip rests on (restated in numpy, float64 as ground truth):
+    x = s (x8 + e), q = t (q8 + f), |e|, |f| <= 1/2  =>  |q.x - t s sum(q8 x8)| <= t s (L1(q8)/2 + L1(x8)/2 + d/4),
+    with the quantisation written the way convert_to_i8_kernel / prep_queries_i8_kernel write it (fp32 scale, rintf, clamp)."""
+    rng = np.random.RandomState(0)
+    d = 768
+
+    def quant(v):
+        v = v.astype(np.float32)
+        mx = np.abs(v).max(axis=1, keepdims=True)
+        sc = np.where(mx > 0, mx / np.float32(127), np.float32(0)).astype(np.float32)
+        inv = np.where(mx > 0, np.float32(127) / mx, np.float32(0)).astype(np.float32)
+        v8 = np.clip(np.rint(v * inv), -127, 127).astype(np.int64)
+        return v8, sc[:, 0].astype(np.float64)
+
+    cases = {
+        "gauss": (rng.randn(300, d), rng.randn(40, d)),
+        "mean": (rng.randn(300, d) + 30.0, rng.randn(40, d) + 5.0),
+        "heavy": (rng.standard_cauchy((300, d)), rng.standard_cauchy((40, d))),
+        "tiny": (rng.randn(300, d) * 1e-6, rng.randn(40, d) * 1e6),
+        "sparse": (rng.randn(300, d) * (rng.rand(300, d) < 0.01), rng.randn(40, d) * (rng.rand(40, d) < 0.05)),
+    }
+    for name, (x, q) in cases.items():
+        x = np.clip(x, -3e4, 3e4)
+        x8, s = quant(x)
+        q8, t = quant(q)
+        true = q.astype(np.float32).astype(np.float64) @ x.astype(np.float32).astype(np.float64).T
+        approx = (q8 @ x8.T) * t[:, None] * s[None, :]
+        bound = t[:, None] * s[None, :] * (0.5 * np.abs(q8).sum(1)[:, None] + 0.5 * np.abs(x8).sum(1)[None, :] + 0.25 * d)
+        assert (np.abs(true - approx) <= bound * 1.001 + 1e-300).all(), name
+        if name == "gauss":  # ... and it is not vacuous: a few tenths of the score spread
+            assert np.median(bound) < 1.0 * true.std()

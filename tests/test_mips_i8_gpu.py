@@ -1,0 +1,129 @@
+"""GPU parity tests (-m gpu) of the int8 screening tier (k = 1, F32X2H storage, d = 768; csrc/mdr_mips.hip, mips_screen8*_kernel):
+whatever the tier does -- decide alone, hand over to the fp16 screen, hand over twice -- ids and scores are those of the exact
+stream kernel, and the telemetry hook says which way it went. Reference: faiss.IndexFlatIP.search as called at
+/root/reference/scripts/eval/eval_mhop_retrieval.py:155,179 (exact inner products, ties to the lowest id)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+D_ = 768
+
+
+@pytest.fixture(scope="module")
+def mdr():
+    from multihop_dense_retrieval_amd import _lib, index
+    _lib.lib()
+    return index
+
+
+def exact(idx, q):
+    idx.set_variant(2)
+    try:
+        return idx.search(q, 1)
+    finally:
+        idx.set_variant(0)
+
+
+def check(idx, q, *, expect_i8_decides=None):
+    De, Ie = exact(idx, q)
+    for v in (0, 4):  # int8 tier in front / fp16 screen alone
+        idx.set_variant(v)
+        D, I = idx.search(q, 1)
+        t = idx.telemetry(q.shape[0], 1)
+        idx.set_variant(0)
+        assert torch.equal(I, Ie), v
+        assert torch.equal(D, De) or float((D - De).abs().max()) <= 2e-6 * float(De.abs().max()) + 1e-30, v
+        assert t["i8_tier"] == (v == 0)
+        if v == 0 and expect_i8_decides is not None:
+            assert (not t["i8_overflow"]) == expect_i8_decides, t
+    return t
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 95, 4097])
+@pytest.mark.parametrize("nq", [1, 100, 130])
+def test_small_and_ragged_indexes(mdr, n, nq):
+    g = torch.Generator(device="cuda").manual_seed(n * 1000 + nq)
+    idx = mdr.IndexFlatIP(D_)
+    idx.add(torch.randn((n, D_), generator=g, device="cuda"))
+    check(idx, torch.randn((nq, D_), generator=g, device="cuda"))
+
+
+def test_no_clear_winner_queries_are_decided_by_the_tier(mdr):
+    """iid queries against iid rows: hundreds of rows per query sit inside the int8 band; most candidates are emitted early against a
+    loose bound and dropped before re-scoring."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    idx = mdr.IndexFlatIP(D_)
+    idx.reserve(600_000)
+    for _ in range(3):  # several add() calls: the plane and its bound constants accumulate
+        idx.add(torch.randn((200_000, D_), generator=g, device="cuda"))
+    for nq in (100, 200, 300):  # 16 queries per wave / 32 per wave / two groups of 256
+        q = torch.randn((nq, D_), generator=g, device="cuda")
+        idx.set_variant(0)
+        idx.search(q, 1)
+        t = idx.telemetry(nq, 1)
+        assert t["i8_tier"] and not t["i8_overflow"] and t["fallback"] == 0
+        assert 0 < t["i8_refined"] <= t["candidates"] * (3 if nq > 256 else 1) + 1  # (k == 1 `candidates` counts the last group only)
+        assert ("mips_screen8w_kernel" if nq > 128 else "mips_screen8_kernel") in idx.last_kernel()
+        check(idx, q, expect_i8_decides=True)
+
+
+def test_growth_keeps_the_int8_plane(mdr):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    idx = mdr.IndexFlatIP(D_)  # no reserve: the planes are re-allocated and copied as the index grows
+    rows = []
+    for n in (1000, 37, 5000, 64):
+        x = torch.randn((n, D_), generator=g, device="cuda")
+        idx.add(x)
+        rows.append(x)
+        q = torch.cat(rows)[-40:] + 0.02 * torch.randn((40, D_), generator=g, device="cuda")
+        check(idx, q, expect_i8_decides=True)
+
+
+def test_rows_and_queries_of_very_different_scales(mdr):
+    """Per-row scales: rows spanning 9 orders of magnitude (F32X2H storage takes |x| <= 32768), an all-zero row, an all-zero query, a query with one huge element."""
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn((20_000, D_), generator=g, device="cuda")
+    x *= torch.logspace(-6, 3, 20_000, device="cuda")[torch.randperm(20_000, generator=g, device="cuda")][:, None]
+    x[123] = 0
+    idx = mdr.IndexFlatIP(D_)
+    idx.add(x)
+    q = torch.randn((64, D_), generator=g, device="cuda")
+    q[5] = 0
+    q[6, 17] = 3e4
+    q[7] *= 1e-20
+    q[8] *= 1e20
+    check(idx, q)
+
+
+def test_loose_bound_hands_over_to_the_fp16_screen(mdr):
+    """Heavy-tailed rows (one element carries the row: its scale wipes out the rest) and rows with a large common mean make the int8
+    bound wide: thousands of survivors per query -> the tier declares itself overflowed and the fp16 screen decides."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    n = 100_000
+    x = torch.randn((n, D_), generator=g, device="cuda")
+    x[torch.arange(n, device="cuda"), torch.randint(0, D_, (n,), generator=g, device="cuda")] = 400.0
+    idx = mdr.IndexFlatIP(D_)
+    idx.add(x)
+    q = torch.randn((100, D_), generator=g, device="cuda")
+    t = check(idx, q)
+    idx.set_variant(0)
+    idx.search(q, 1)
+    t = idx.telemetry(100, 1)
+    assert t["i8_tier"] and t["i8_overflow"], t
+    assert t["fallback"] == 0, t  # ... and the fp16 screen behind it needs no exact pass
+
+
+def test_env_switch_leaves_the_plane_out(mdr, monkeypatch):
+    """MDR_MIPS_I8=0 is read once per process, so this only checks the variant-4 spelling of the same thing."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    idx = mdr.IndexFlatIP(D_)
+    idx.add(torch.randn((5000, D_), generator=g, device="cuda"))
+    q = torch.randn((10, D_), generator=g, device="cuda")
+    idx.set_variant(4)
+    idx.search(q, 1)
+    assert "mips_screen_kernel" in idx.last_kernel() and not idx.telemetry(10, 1)["i8_tier"]
+    idx.set_variant(0)
+    idx.search(q, 1)
+    assert "mips_screen8_kernel" in idx.last_kernel()
