@@ -1765,7 +1765,7 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
         }
         if (it + NS - 1 < n_it) issue_super_block8<NKB8>(X8, b + (it + NS - 1) * G, lds + ((it + NS - 1) % NS) * SB_BYTES, wave, lane);
         stamp(1);
-        if (!wave_active) continue;
+        if (!wave_active || MDR_I8_ABL == 5) continue;
 
         const int sb_idx = b + it * G;
         const char* slot = lds + (it % NS) * SB_BYTES;
@@ -1774,8 +1774,15 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
 #pragma unroll
         for (int j = 0; j < 4; ++j) sr[j] = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + (8 * j + 4 * lh) * 4);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]));
-        const i32x16 acc = mfma_chain8x32<NKB8>(slot + rd_off, qf);
+        i32x16 acc;
+        if (MDR_I8_ABL == 3) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = qf[e][0] + it;
+        } else {
+            acc = mfma_chain8x32<NKB8>(slot + rd_off, qf);
+        }
         stamp(2);
+        if (MDR_I8_ABL == 2) { if (q_valid) lmax = fmaxf(lmax, (float)(acc[0] + acc[5] + acc[10] + acc[15])); continue; }
         epilogue(acc, sr, sb_idx);
         stamp(3);
     }
