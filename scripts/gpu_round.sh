@@ -31,7 +31,7 @@ S=$(find $OUT/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && (c
 rm -rf $OUT/prof_stats
 echo "== rocprofv3 pmc FETCH_SIZE (1M, MIPS only)"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_pmc -o mips1m -- python $REPO/bench.py --rows 1000000 --steps 3 --warmup 1 --no-encoder --no-cpu-baseline $EXTRA > $OUT/prof_pmc.log 2>&1
-P=$(find $OUT/prof_pmc -name "*counter_collection.csv" | head -1); [ -n "$P" ] && (head -1 "$P" > $OUT/pmc_fetch_size.csv; grep -E "mips_s(creen|tream)_kernel" "$P" >> $OUT/pmc_fetch_size.csv; head -3 $OUT/pmc_fetch_size.csv | cut -c1-300)
+P=$(find $OUT/prof_pmc -name "*counter_collection.csv" | head -1); [ -n "$P" ] && (head -1 "$P" > $OUT/pmc_fetch_size.csv; grep -E "mips_(screen|screen8|screen8w|screen32|stream)_kernel" "$P" >> $OUT/pmc_fetch_size.csv; head -3 $OUT/pmc_fetch_size.csv | cut -c1-300)
 rm -rf $OUT/prof_pmc
 # keep the transfer small: drop the big traces, keep csv summaries
 find $OUT -name "*.db" -size +20M -delete 2>/dev/null
