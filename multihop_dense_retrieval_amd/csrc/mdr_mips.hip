@@ -1618,9 +1618,22 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
 // 96 registers of resident query slices instead of 192. Reads and their counted waits are hand-placed as in mfma_chain32.
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
-template <int NKB8>
-__device__ __forceinline__ i32x16 mfma_chain8x32(const char* p, const i32x4 (&qf)[2 * NKB8]) {
-    constexpr int NSL = 2 * NKB8, PF = 4;
+// `fill(sl)` is called behind MFMA sl and pinned there: the caller's VALU work (the epilogue of the PREVIOUS super-block) issues in
+// the shadow of the 32-cycle MFMAs instead of after the chain.
+#ifndef MDR_I8W_PF
+#define MDR_I8W_PF 4  // fragment reads in flight ahead of the MFMA that consumes them (<= 8)
+#endif
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& fn) {  // fn(std::integral_constant<int, I>{}) for I = I .. N-1: indices stay compile-time constants
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(fn);
+    }
+}
+
+template <int NKB8, typename F>
+__device__ __forceinline__ i32x16 mfma_chain8x32(const char* p, const i32x4 (&qf)[2 * NKB8], F&& fill) {
+    constexpr int NSL = 2 * NKB8, PF = MDR_I8W_PF;
     const unsigned a = (unsigned)(uintptr_t)p;
     i32x16 acc;
 #pragma unroll
@@ -1628,19 +1641,23 @@ __device__ __forceinline__ i32x16 mfma_chain8x32(const char* p, const i32x4 (&qf
     i32x4 xa[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[i]) : "v"(a), "n"((i >> 1) * kFragBytes + (i & 1) * 512));
-#pragma unroll
-    for (int sl = 0; sl < NSL; ++sl) {
-        const int left = NSL - 1 - sl < PF - 1 ? NSL - 1 - sl : PF - 1;  // reads younger than the one needed now
-        switch (left) {
-            case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xa[sl % PF])); break;
-            case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xa[sl % PF])); break;
-            case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xa[sl % PF])); break;
-            default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[sl % PF])); break;
-        }
+    static_for<0, NSL>([&](auto slc) __attribute__((always_inline)) {
+        constexpr int sl = decltype(slc)::value;
+        constexpr int left = NSL - 1 - sl < PF - 1 ? NSL - 1 - sl : PF - 1;  // reads younger than the one needed now
+        if constexpr (left == 7) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(xa[sl % PF]));
+        else if constexpr (left == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(xa[sl % PF]));
+        else if constexpr (left == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(xa[sl % PF]));
+        else if constexpr (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xa[sl % PF]));
+        else if constexpr (left == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xa[sl % PF]));
+        else if constexpr (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xa[sl % PF]));
+        else if constexpr (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xa[sl % PF]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[sl % PF]));
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[sl % PF], qf[sl], acc, 0, 0, 0);
-        if (sl + PF < NSL)
+        if constexpr (sl + PF < NSL)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[sl % PF]) : "v"(a), "n"(((sl + PF) >> 1) * kFragBytes + ((sl + PF) & 1) * 512));
-    }
+        fill(slc);
+        __builtin_amdgcn_sched_barrier(0);
+    });
     return acc;
 }
 
@@ -1654,17 +1671,24 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
                      unsigned* __restrict__ gmax, u64* __restrict__ cand, int* __restrict__ cand_cnt, int* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SB_BYTES = 2 * NKB8 * kFragBytes + kI8Tail;
-    constexpr int CPW = NKB8 / 4;
+    constexpr int SPS = 2;                   // super-blocks per stage: ONE barrier and one burst of DMA issue per 64 rows
+    constexpr int ST_BYTES = SPS * SB_BYTES;
+    constexpr int CPW = SPS * (NKB8 / 4);    // DMA pieces per wave and stage (wave 0: + SPS scale tails)
     constexpr int NSL = 2 * NKB8;  // 32-deep K slices
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = gridDim.x, b = blockIdx.x;
-    int n_it = (n_sb - b + G - 1) / G;
+    const int n_st = (n_sb + SPS - 1) / SPS;  // (the plane is allocated to a whole number of stages)
+    int n_it = (n_st - b + G - 1) / G;
     if (MODE == 0 && n_it > kSampleStages) n_it = kSampleStages;
+    auto issue_stage = [&](int stg, char* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < SPS; ++h) issue_super_block8<NKB8>(X8, SPS * stg + h, dst + h * SB_BYTES, wave, lane);
+    };
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i)
-        if (i < n_it) issue_super_block8<NKB8>(X8, b + i * G, lds + i * SB_BYTES, wave, lane);
+        if (i < n_it) issue_stage(b + i * G, lds + i * ST_BYTES);
 
     const bool wave_active = wave * 32 < nq;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -1695,37 +1719,60 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
     const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const int rd_off = ((lane >> 4) & 1) * (NKB8 * kFragBytes) + lh * 256 + (lane & 15) * 16;
 
-    auto epilogue = [&](const i32x16& acc, const f32x4 (&sr)[4], int sb_idx) __attribute__((always_inline)) {
-        f32x2 u2[8];
+    // The epilogue of a super-block runs INSIDE the MFMA chain of the next one (software pipelining within the wave): `bounds` turns
+    // two accumulators of the other super-block into upper bounds, `decide` tests them; mfma_chain8x32 calls them behind its first
+    // nine MFMAs. The two super-blocks of a stage own one accumulator set each (P[0], P[1]), so nothing is copied and the chain
+    // of one never waits for the last MFMA of the other to drain.
+    struct Pending {
+        i32x16 acc;
+        f32x4 sr[4];
+        int sb;
+        bool have;
+    };
+    Pending P[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x2 f0 = {(float)acc[4 * j], (float)acc[4 * j + 1]}, f1 = {(float)acc[4 * j + 2], (float)acc[4 * j + 3]};
-            const f32x2 s0 = {sr[j][0], sr[j][1]}, s1 = {sr[j][2], sr[j][3]};
-            u2[2 * j] = __builtin_elementwise_fma(__builtin_elementwise_fma(f0, qt2, qa2), s0, qb2);
-            u2[2 * j + 1] = __builtin_elementwise_fma(__builtin_elementwise_fma(f1, qt2, qa2), s1, qb2);
-        }
-        float up[16];
+    for (int h = 0; h < 2; ++h) {
+        P[h].have = false;
+        P[h].sb = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) up[r] = u2[r >> 1][r & 1];
-        float mu = up[0], smax = sr[0][0];
+        for (int e = 0; e < 16; ++e) P[h].acc[e] = 0;
 #pragma unroll
-        for (int r = 1; r < 16; ++r) { mu = fmaxf(mu, up[r]); smax = fmaxf(smax, sr[r >> 2][r & 3]); }
-        const unsigned row0 = (unsigned)sb_idx * 32u + 4u * (unsigned)lh;
-        const bool whole = (long long)sb_idx * 32 + 32 <= n_rows;  // wave-uniform
+        for (int j = 0; j < 4; ++j) P[h].sr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x2 u2[8];
+    float mu = -FLT_MAX;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u2[j] = (f32x2){0.f, 0.f};
+    auto bounds = [&](const Pending& R, auto jc) __attribute__((always_inline)) {  // accumulators 2 j, 2 j + 1 of super-block R
+        constexpr int j = decltype(jc)::value;
+        const f32x2 f = {(float)R.acc[2 * j], (float)R.acc[2 * j + 1]};
+        const f32x2 sc = {R.sr[j >> 1][2 * (j & 1)], R.sr[j >> 1][2 * (j & 1) + 1]};
+        u2[j] = __builtin_elementwise_fma(__builtin_elementwise_fma(f, qt2, qa2), sc, qb2);
+        mu = j == 0 ? fmaxf(u2[0][0], u2[0][1]) : fmaxf(mu, fmaxf(u2[j][0], u2[j][1]));
+    };
+    auto decide = [&](Pending& R) __attribute__((always_inline)) {
+        if (!R.have) return;
+        R.have = false;
+        float smax = R.sr[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) smax = fmaxf(smax, R.sr[r >> 2][r & 3]);
+        const unsigned row0 = (unsigned)R.sb * 32u + 4u * (unsigned)lh;
+        const bool whole = (long long)R.sb * 32 + 32 <= n_rows;  // wave-uniform
         if (whole && (MODE != 1 || __ballot(q_valid && mu >= known) == 0ull)) {
             if (q_valid) lmax = fmaxf(lmax, mu - 2.f * fmaf(qa, smax, qb));
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                const float up = u2[r >> 1][r & 1];
                 const unsigned row = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
                 const bool ok = (long long)row < n_rows && q_valid;
-                if (ok) lmax = fmaxf(lmax, up[r] - 2.f * fmaf(qa, sr[r >> 2][r & 3], qb));
+                if (ok) lmax = fmaxf(lmax, up - 2.f * fmaf(qa, R.sr[r >> 2][r & 3], qb));
                 if (MODE == 1) {
-                    const bool hit = ok && up[r] >= known;
+                    const bool hit = ok && up >= known;
                     const u64 m = __ballot(hit);
                     if (m) {  // wave-uniform
                         const int slot_i = my_cnt + __popcll(m & lt);
-                        if (hit && slot_i < kWaveCandCap) my_list[slot_i] = pack_cand8(q_base + qlocal, up[r], row);
+                        if (hit && slot_i < kWaveCandCap) my_list[slot_i] = pack_cand8(q_base + qlocal, up, row);
                         my_cnt += __popcll(m);
                     }
                 }
@@ -1745,7 +1792,7 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
     stamp(-1);
     for (int it = 0; it < n_it; ++it) {
         if (it + NS - 2 < n_it) {
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((CPW + 1) * (NS - 2)) : "memory");
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((CPW + SPS) * (NS - 2)) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CPW * (NS - 2)) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1763,28 +1810,45 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
             }
             known = __shfl(kn, l31);
         }
-        if (it + NS - 1 < n_it) issue_super_block8<NKB8>(X8, b + (it + NS - 1) * G, lds + ((it + NS - 1) % NS) * SB_BYTES, wave, lane);
+        if (it + NS - 1 < n_it && MDR_I8_ABL != 6) issue_stage(b + (it + NS - 1) * G, lds + ((it + NS - 1) % NS) * ST_BYTES);
         stamp(1);
         if (!wave_active || MDR_I8_ABL == 5) continue;
 
-        const int sb_idx = b + it * G;
-        const char* slot = lds + (it % NS) * SB_BYTES;
-        // this lane's 16 row scales: rows 8 j + 4 lh .. + 3, j = 0..3
-        f32x4 sr[4];
+        static_for<0, SPS>([&](auto hc) __attribute__((always_inline)) {
+            constexpr int h = decltype(hc)::value;
+            Pending& Wp = P[h];      // this super-block's accumulator set
+            Pending& Rp = P[h ^ 1];  // the one whose epilogue is still pending: the super-block before this one
+            const int sb_idx = SPS * (b + it * G) + h;
+            if (sb_idx >= n_sb) return;  // wave-uniform: the corpus ends inside this stage
+            const char* slot = lds + (it % NS) * ST_BYTES + h * SB_BYTES;
+            // this lane's 16 row scales: rows 8 j + 4 lh .. + 3, j = 0..3
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sr[j] = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + (8 * j + 4 * lh) * 4);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]));
-        i32x16 acc;
-        if (MDR_I8_ABL == 3) {
+            for (int j = 0; j < 4; ++j) Wp.sr[j] = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + (8 * j + 4 * lh) * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Wp.sr[0]), "+v"(Wp.sr[1]), "+v"(Wp.sr[2]), "+v"(Wp.sr[3]));
+            if (MDR_I8_ABL == 3) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = qf[e][0] + it;
-        } else {
-            acc = mfma_chain8x32<NKB8>(slot + rd_off, qf);
-        }
+                for (int e = 0; e < 16; ++e) Wp.acc[e] = qf[e][0] + it;
+            } else {
+                Wp.acc = mfma_chain8x32<NKB8>(slot + rd_off, qf, [&](auto slc) __attribute__((always_inline)) {
+                    constexpr int sl = decltype(slc)::value;
+                    if constexpr (MDR_I8_ABL != 2) {
+                        if constexpr (sl < 8) bounds(Rp, slc);
+                        else if constexpr (sl == 8) decide(Rp);
+                    }
+                });
+            }
+            Wp.sb = sb_idx;
+            Wp.have = true;
+        });
         stamp(2);
-        if (MDR_I8_ABL == 2) { if (q_valid) lmax = fmaxf(lmax, (float)(acc[0] + acc[5] + acc[10] + acc[15])); continue; }
-        epilogue(acc, sr, sb_idx);
-        stamp(3);
+    }
+    if (wave_active && MDR_I8_ABL != 2 && MDR_I8_ABL != 5) {  // the last super-block's epilogue (at most one is pending)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (P[h].have) {
+                static_for<0, 8>([&](auto jc) __attribute__((always_inline)) { bounds(P[h], jc); });
+                decide(P[h]);
+            }
     }
     if (MDR_I8_ABL == 9 && MODE == 1 && threadIdx.x == 0) {
 #pragma unroll
@@ -2045,7 +2109,7 @@ int grow(mdr_index* h, long long need_rows, hipStream_t st) {
     }
     char* n8 = nullptr;
     if (wants_i8(h)) {
-        const size_t sbb = i8_sb_bytes(h->d / 64), nb8 = (size_t)(ncap / 32) * sbb, used8 = (size_t)(pad32(h->ntotal) / 32) * sbb;
+        const size_t sbb = i8_sb_bytes(h->d / 64), nb8 = (size_t)(ncap / 32 + 1) * sbb, used8 = (size_t)(pad32(h->ntotal) / 32) * sbb;  // + 1: the wide kernel's stages are super-block pairs
         MDR_HIP_TRY(hipMalloc((void**)&n8, nb8));
         if (used8) MDR_HIP_TRY(hipMemcpyAsync(n8, h->i8, used8, hipMemcpyDeviceToDevice, st));
         MDR_HIP_TRY(hipMemsetAsync(n8 + used8, 0, nb8 - used8, st));
@@ -2123,7 +2187,7 @@ struct SearchPlan {
 };
 
 #ifndef MDR_I8W_SLOTS
-#define MDR_I8W_SLOTS 6  // the 32-queries-per-wave int8 kernel needs 178 VGPRs: ONE workgroup per CU, so its ring is deep instead (5 stages = 121 KiB in flight)
+#define MDR_I8W_SLOTS 3  // the 32-queries-per-wave int8 kernel needs > 128 VGPRs: ONE workgroup per CU; its stages are 64 rows (48.5 KiB), two in flight
 #endif
 #ifndef MDR_I8_SLOTS
 #define MDR_I8_SLOTS 3  // variant-build knob: LDS ring depth of the int8 screen kernels (3: two workgroups per CU, 4-6: one)
@@ -2165,7 +2229,7 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     {
         const long long per_cu = MDR_I8_SLOTS <= 3 ? 2 : 1;  // workgroups of the int8 kernels per CU (LDS: 3 slots are 73 KiB, 6 are 146 KiB)
         p.G8 = (int)(units < per_cu * h->num_cus ? (units > 0 ? units : 1) : per_cu * h->num_cus);
-        p.G8w = p.G;  // the 32-queries-per-wave kernel: one per CU
+        p.G8w = (int)((units + 1) / 2 < h->num_cus ? ((units + 1) / 2 > 0 ? (units + 1) / 2 : 1) : h->num_cus);  // the 32-queries-per-wave kernel: one per CU, stages of two super-blocks
     }
     const size_t gl = p.i8 && p.G8 > p.G ? (size_t)p.G8 : (size_t)p.G;  // workgroups that own candidate lists
     p.off_scand = take(p.path != PATH_SCREEN ? 0 : (k == 1 ? gl * 8 * kWaveCandCap * 8 : (size_t)p.G * kWideQ * 4));
@@ -2309,7 +2373,7 @@ int run_screen32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
 // k == 1, more than 128 queries, int8 plane present: the int8 tier per group of 256 queries
 int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, u64* best, hipStream_t st) {
     constexpr int NKB8 = 12, NS = MDR_I8W_SLOTS;
-    const size_t lds_bytes = NS * (size_t)(2 * NKB8 * kFragBytes + kI8Tail);
+    const size_t lds_bytes = NS * 2 * (size_t)(2 * NKB8 * kFragBytes + kI8Tail);  // a stage of this kernel = two super-blocks
     int rc_ = ensure_dynamic_lds((const void*)mips_screen8w_kernel<NKB8, 0, NS>, (int)lds_bytes);
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen8w_kernel<NKB8, 1, NS>, (int)lds_bytes);
     if (rc_) return rc_;
