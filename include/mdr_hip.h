@@ -46,7 +46,9 @@ extern "C" {
 #define MDR_DT_F16 2
 
 /* index storage formats */
-#define MDR_STORE_F32X2H 0  /* fp32-accurate: each element kept as an fp16 (hi, lo) pair = 4 bytes  */
+#define MDR_STORE_F32X2H 0  /* fp32-accurate: each element kept as an fp16 (hi, lo) pair = 4 bytes; d = 768 indexes also carry an int8
+                             * screening copy (1 byte per element + 4 per row, +25 % device memory) that k = 1 searches stream first --
+                             * results do not depend on it (environment MDR_MIPS_I8=0 at creation leaves it out) */
 #define MDR_STORE_BF16 1    /* rows rounded to bf16 (RNE), 2 bytes per element; scores exact w.r.t. the rounded rows */
 
 const char* mdr_last_error(void);
