@@ -195,6 +195,11 @@ def verify_full_size(out, lo, hi, n_total, d, device, beam, bf16_rows=False):
     return res
 
 
+def calls_nq(pipe):
+    calls = pipe.search_calls()
+    return int(calls[-1][1]) if calls else 0
+
+
 def mips_roofline(pipe, local, args, d):
     """Roofline entry of the MIPS kernel from the timed search calls of `pipe`: PHYSICAL HBM bytes / HIP-event time of each whole
     search call / 8 TB/s (the fp32-equivalent "algorithmic" rate under its own key)."""
@@ -451,6 +456,11 @@ def main():
                      "TFLOPs": round((e2 + (e1 if pipe.pipelined else 0)) / (stage["hop2_encode"] * 1e-3) / 1e12, 1)},
             "share_of_step": round(enc_ms / ms_per_step, 3),
             "note": "executed FLOPs (masked tokens dropped, last layer CLS-only) / HIP-event stage time on the launch stream; peak = dense fp16 MFMA"}
+    if hasattr(local, "telemetry") and calls_nq(pipe):  # which screening tier decided the LAST search of the timed region (test hook; outside it)
+        t = local.telemetry(calls_nq(pipe), args.beam)
+        result["mips_tiers"] = {"int8_tier_ran": t["i8_tier"], "int8_tier_handed_over": t["i8_overflow"], "exact_fallback_ran": bool(t["fallback"]),
+                                "candidates_emitted_last_group": t["candidates"], "candidates_rescored": t["i8_refined"] if t["i8_tier"] else t["candidates"],
+                                "kernel": local.last_kernel()}
     result["stage_share"] = {"encoder": round((stage.get("hop1_encode", 0) + stage.get("hop2_encode", 0)) / ms_per_step, 3),
                              "mips": round((stage.get("hop1_search", 0) + stage.get("hop2_search", 0)) / ms_per_step, 3)}
 
