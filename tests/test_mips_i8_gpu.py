@@ -127,3 +127,36 @@ def test_env_switch_leaves_the_plane_out(mdr, monkeypatch):
     idx.set_variant(0)
     idx.search(q, 1)
     assert "mips_screen8_kernel" in idx.last_kernel()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_differential_against_the_exact_kernel(mdr, seed):
+    """Random sizes, query counts and data families (gaussian, uniform, sparse, low-rank + noise, clustered with exact duplicates and
+    near-duplicates, mixed scales): the k = 1 answer of the tiered search is the exact kernel's, whichever tier decides."""
+    rng = np.random.RandomState(1000 + seed)
+    g = torch.Generator(device="cuda").manual_seed(2000 + seed)
+    n = int(rng.choice([257, 4096, 33_333, 120_001, 300_000]))
+    nq = int(rng.choice([1, 17, 100, 128, 129, 200, 256, 257, 300]))
+    fam = ["gauss", "uniform", "sparse", "lowrank", "clusters", "scales"][seed % 6]
+    x = torch.randn((n, D_), generator=g, device="cuda")
+    if fam == "uniform":
+        x = torch.rand((n, D_), generator=g, device="cuda") - 0.3
+    elif fam == "sparse":
+        x = x * (torch.rand((n, D_), generator=g, device="cuda") < 0.05)
+    elif fam == "lowrank":
+        x = torch.randn((n, 8), generator=g, device="cuda") @ torch.randn((8, D_), generator=g, device="cuda") + 0.05 * x
+    elif fam == "clusters":
+        c = torch.randn((50, D_), generator=g, device="cuda")
+        x = c[torch.randint(0, 50, (n,), generator=g, device="cuda")] + 0.01 * x
+        x[n // 2] = x[3]                      # an exact duplicate: lowest id wins
+        x[n // 3] = x[3] * (1 - 1e-5)         # and a near-duplicate
+    elif fam == "scales":
+        x = x * torch.exp(4 * torch.randn((n, 1), generator=g, device="cuda"))
+        x = x.clamp(-3e4, 3e4)
+    idx = mdr.IndexFlatIP(D_)
+    idx.add(x.contiguous())
+    q = torch.randn((nq, D_), generator=g, device="cuda")
+    if fam in ("clusters", "lowrank"):
+        q[: min(nq, 8)] = x[torch.randint(0, n, (min(nq, 8),), generator=g, device="cuda")] + 0.001 * q[: min(nq, 8)]
+        q[0] = x[3]
+    check(idx, q.contiguous())
