@@ -1903,6 +1903,9 @@ mips_refine8_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, 
         const u64 e = list[c];
         const unsigned qi = (unsigned)(e >> 48), u16 = (unsigned)(e >> 32) & 0xFFFFu, row = (unsigned)e;
         if (u16 < (gmax[qi] >> 16)) continue;  // U < final max L: cannot be the best row
+        // ... nor can a row whose upper bound lies below an EXACT score some other candidate of this query already reached (`best` only
+        // rises; an equal score survives, so the lowest id still wins ties)
+        if (u16 < (unsigned)(load_key_l2(best + qi) >> 48)) continue;
         const float acc = exact_dot16<false>(Xhi, Xlo, nkb, q + (size_t)qi * d, row, sub);
         if (sub == 0) { atomicMax(best + qi, make_key(acc, row)); ++kept; }
     }
