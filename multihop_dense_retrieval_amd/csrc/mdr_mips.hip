@@ -1316,7 +1316,7 @@ mips_generic_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, 
 #ifndef MDR_I8_ABL
 #define MDR_I8_ABL 0  // measurement builds (wrong results): 1 no scale-tail DMA, 2 no epilogue, 3 no MFMAs, 4 no fragment reads
 #endif
-constexpr int kI8RefinePerQuery = 2048;  // survivors per query of a pass beyond which the int8 tier hands over to the fp16 screen (see mips_refine8_kernel)
+constexpr int kI8RefinePerQuery = 8192;  // emitted candidates per query of a pass beyond which the int8 tier hands over to the fp16 screen (see mips_refine8_kernel)
 constexpr int kI8Tail = 256;  // bytes behind a super-block's fragments: 32 fp32 row scales (+ padding to one 4-byte-per-lane DMA piece)
 #ifndef MDR_I8_ALIGN
 #define MDR_I8_ALIGN 256  // variant-build knob: alignment of a super-block's start in the int8 plane
@@ -1608,6 +1608,7 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
     if (MODE == 1 && lane == 0) {
         cand_cnt[b * 8 + wave] = my_cnt < kWaveCandCap ? my_cnt : kWaveCandCap;
         if (my_cnt > kWaveCandCap) *overflow = 1;
+        if (my_cnt) atomicAdd(overflow + 3, my_cnt);  // ctl8[3]: candidates emitted by this pass (the refinement's guard)
     }
 }
 
@@ -1862,34 +1863,20 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
     if (MODE == 1 && lane == 0) {
         cand_cnt[b * 8 + wave] = my_cnt < kWaveCandCap ? my_cnt : kWaveCandCap;
         if (my_cnt > kWaveCandCap) *overflow = 1;
+        if (my_cnt) atomicAdd(overflow + 3, my_cnt);  // ctl8[3]: candidates emitted by this pass (the refinement's guard)
     }
 }
 
 // exact re-scoring of the int8 tier's candidates: as mips_refine_kernel, after dropping every candidate whose (rounded-up) upper
 // bound lies below the FINAL largest lower bound of its query -- most of a no-clear-winner query's candidates were emitted early,
 // against a `known` that the pass later raised. ctl8[1] counts the candidates that are really re-scored.
-// How many of the int8 tier's candidates survive that filter (ctl8[2]); one block per list.
-__global__ void __launch_bounds__(256)
-mips_count8_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_cnt, const unsigned* __restrict__ gmax, int* __restrict__ ctl8) {
-    __shared__ int red[4];
-    const int n = cand_cnt[blockIdx.x];
-    if (n == 0) return;
-    const u64* list = cand + (size_t)blockIdx.x * kWaveCandCap;
-    int c = 0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const u64 e = list[i];
-        c += ((unsigned)(e >> 32) & 0xFFFFu) >= (gmax[(unsigned)(e >> 48)] >> 16);
-    }
-    c = block_sum_256(c, red);
-    if (threadIdx.x == 0 && c) atomicAdd(ctl8 + 2, c);
-}
-
-// `limit`: survivors beyond which re-scoring them one by one would cost more than the fp16 screen pass behind this tier (data for
-// which the int8 bound is loose: rows with a large common mean, all-ties corpora): the tier then declares itself overflowed.
+// `limit`: emitted candidates (ctl8[3], summed by the main pass) beyond which filtering and re-scoring them would cost more than the
+// fp16 screen pass behind this tier (data for which the int8 bound is loose: rows with a large common mean, all-ties corpora):
+// the tier then declares itself overflowed.
 __global__ void __launch_bounds__(256)
 mips_refine8_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, const u64* __restrict__ cand,
                     const int* __restrict__ cand_cnt, const unsigned* __restrict__ gmax, u64* __restrict__ best, int* __restrict__ ctl8, int limit) {
-    if (ctl8[0] || ctl8[2] > limit) {
+    if (ctl8[0] || ctl8[3] > limit) {
         if (blockIdx.x == 0 && threadIdx.x == 0) ctl8[0] = 1;
         return;
     }
@@ -2332,7 +2319,6 @@ int run_screen8(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
                        (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8);
     hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 1, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
                        (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8);
-    hipLaunchKernelGGL(mips_count8_kernel, dim3(p.G8 * 8), dim3(256), 0, st, (const u64*)scand, (const int*)wave_cnt, (const unsigned*)gmax, ctl8);
     hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8 * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
                        (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nq);
     MDR_HIP_TRY(hipGetLastError());
@@ -2395,12 +2381,11 @@ int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
     for (int gi = 0; gi < ngroups; ++gi) {
         const int nqg = nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ;
         const char* qg = q8 + (size_t)gi * kWideQ * h->d;
+        if (gi) MDR_HIP_TRY(hipMemsetAsync(ctl8 + 3, 0, sizeof(int), st));  // emitted-candidate total of this group's pass
         hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 0, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
                            (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8);
         hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 1, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
                            (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8);
-        MDR_HIP_TRY(hipMemsetAsync(ctl8 + 2, 0, sizeof(int), st));
-        hipLaunchKernelGGL(mips_count8_kernel, dim3(p.G8w * 8), dim3(256), 0, st, (const u64*)scand, (const int*)wave_cnt, (const unsigned*)gmax, ctl8);
         hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8w * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
                            (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nqg);
         MDR_HIP_TRY(hipGetLastError());

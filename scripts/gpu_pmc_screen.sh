@@ -13,7 +13,7 @@ for MODE in sequential pipelined; do
     N=$(echo $PMC | tr ' ' '_' | cut -c1-30)
     timeout 300 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/p -o p -- python $REPO/bench.py --rows 5000000 --steps 3 --warmup 1 --no-encoder --no-cpu-baseline --no-sequential --no-verify $FLAG > $OUT/log_${MODE}_$N.txt 2>&1
     P=$(find $OUT/p -name "*counter_collection.csv" | head -1)
-    if [ -n "$P" ]; then head -1 "$P" > $OUT/${MODE}_$N.csv; grep -E "mips_(screen|screen32|screen8|screen8w|refine|refine8|count8)" "$P" >> $OUT/${MODE}_$N.csv; fi
+    if [ -n "$P" ]; then head -1 "$P" > $OUT/${MODE}_$N.csv; grep -E "mips_(screen|screen32|screen8|screen8w|refine|refine8)" "$P" >> $OUT/${MODE}_$N.csv; fi
     rm -rf $OUT/p
   done
 done
