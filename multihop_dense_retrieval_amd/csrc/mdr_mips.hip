@@ -1885,16 +1885,27 @@ mips_refine8_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, 
     const u64* list = cand + (size_t)blockIdx.x * kWaveCandCap;
     const int sub = threadIdx.x & 15;
     const int d = nkb * 32;
+    // A list belongs to ONE wave of the screen kernel: its candidates share at most 32 consecutive queries (aligned to 32). thr[] is
+    // this block's copy of "an exact score somebody already reached for that query" (top 16 bits of the ordered score): seeded from
+    // `best` once, raised by this block's own re-scorings. A row whose upper bound lies below it cannot win (an equal score survives,
+    // so the lowest id still wins ties). (Reading `best` itself per candidate -- 4e5 uncached loads of 200 hot words -- doubled the
+    // kernel's time.)
+    __shared__ unsigned thr[32];
+    const unsigned qb32 = (unsigned)(list[0] >> 48) & ~31u;
+    if (threadIdx.x < 32) thr[threadIdx.x] = (unsigned)(best[qb32 + threadIdx.x] >> 48);
+    __syncthreads();
     int kept = 0;
     for (int c = threadIdx.x >> 4; c < n; c += 16) {
         const u64 e = list[c];
         const unsigned qi = (unsigned)(e >> 48), u16 = (unsigned)(e >> 32) & 0xFFFFu, row = (unsigned)e;
         if (u16 < (gmax[qi] >> 16)) continue;  // U < final max L: cannot be the best row
-        // ... nor can a row whose upper bound lies below an EXACT score some other candidate of this query already reached (`best` only
-        // rises; an equal score survives, so the lowest id still wins ties)
-        if (u16 < (unsigned)(load_key_l2(best + qi) >> 48)) continue;
+        if (u16 < thr[qi & 31]) continue;
         const float acc = exact_dot16<false>(Xhi, Xlo, nkb, q + (size_t)qi * d, row, sub);
-        if (sub == 0) { atomicMax(best + qi, make_key(acc, row)); ++kept; }
+        if (sub == 0) {
+            atomicMax(best + qi, make_key(acc, row));
+            atomicMax(&thr[qi & 31], ord32(acc) >> 16);
+            ++kept;
+        }
     }
     if (sub == 0 && kept) atomicAdd(ctl8 + 1, kept);
 }
