@@ -1454,7 +1454,7 @@ template <int NKB8, int MODE, int NS>  // NS: LDS slots of one super-block (NS -
 __global__ void __launch_bounds__(512, 2)
 mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, const char* __restrict__ Q8, const f32x4* __restrict__ qab, int nq, int q_base,
                     unsigned* __restrict__ gmax /* [nq] ordered(max L) */, u64* __restrict__ cand /* [waves][kWaveCandCap] */,
-                    int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow) {
+                    int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow, u64* __restrict__ gstar /* [nq] (ordered max L, its row) */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SB_BYTES = 2 * NKB8 * kFragBytes + kI8Tail;
     constexpr int CPW = NKB8 / 4;  // DMA pieces per wave and stage (wave 0: + 1, the scale tail)
@@ -1494,6 +1494,7 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
     const f32x2 qt2 = {qt, qt}, qa2 = {qa, qa}, qb2 = {qb, qb};
     const unsigned sub_row = 4u * (unsigned)(lane >> 4);
     float lmax = -FLT_MAX;  // largest lower bound this lane has seen
+    unsigned lrow = 0;      // ... and the row it belongs to: the refinement re-scores that row first (see mips_star8_kernel)
     int my_cnt = 0;
     u64* my_list = cand + ((size_t)b * 8 + wave) * kWaveCandCap;
     const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -1572,7 +1573,13 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
         const float mu = fmaxf(fmaxf(fmaxf(up[0], up[1]), fmaxf(up[2], up[3])), fmaxf(fmaxf(up[4], up[5]), fmaxf(up[6], up[7])));
         const float smax = fmaxf(fmaxf(fmaxf(sr0[0], sr0[1]), fmaxf(sr0[2], sr0[3])), fmaxf(fmaxf(sr1[0], sr1[1]), fmaxf(sr1[2], sr1[3])));
         if (whole && (MODE != 1 || __ballot(q_valid && mu >= known) == 0ull)) {
-            if (q_valid) lmax = fmaxf(lmax, mu - 2.f * fmaf(qa, smax, qb));
+            const float cl = mu - 2.f * fmaf(qa, smax, qb);
+            if (q_valid && cl > lmax) {  // a new record for this lane (O(log rows) times per pass): remember the row
+                lmax = cl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (up[e] == mu) lrow = row0 + 16u * (e >> 2) + (e & 3);
+            }
         } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -1580,7 +1587,8 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
                 for (int r = 0; r < 4; ++r) {
                     const unsigned row = row0 + 16u * h + r;
                     const bool ok = (long long)row < n_rows && q_valid;
-                    if (ok) lmax = fmaxf(lmax, up[4 * h + r] - 2.f * fmaf(qa, h ? sr1[r] : sr0[r], qb));
+                    const float lr_ = up[4 * h + r] - 2.f * fmaf(qa, h ? sr1[r] : sr0[r], qb);
+                    if (ok && lr_ > lmax) { lmax = lr_; lrow = row; }
                     if (MODE == 1) {
                         const bool hit = ok && up[4 * h + r] >= known;
                         const u64 m = __ballot(hit);
@@ -1600,10 +1608,11 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
         }
     }
     {   // both modes publish: after the main pass gmax holds the largest lower bound over ALL rows, which lets the refinement drop
-        // the candidates that were emitted against an early, loose `known`
+        // the candidates that were emitted against an early, loose `known`; gstar also names the row that bound belongs to
         float hm = fmaxf(lmax, __shfl_xor(lmax, 16));
         hm = fmaxf(hm, __shfl_xor(hm, 32));
         if (lane < 16 && q_valid && hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
+        if (q_valid && lmax == hm && hm > -FLT_MAX) atomicMax(gstar + qlocal, ((u64)ord32(lmax) << 32) | lrow);
     }
     if (MODE == 1 && lane == 0) {
         cand_cnt[b * 8 + wave] = my_cnt < kWaveCandCap ? my_cnt : kWaveCandCap;
@@ -1669,7 +1678,7 @@ __device__ unsigned long long g_i8_stamp[8];
 template <int NKB8, int MODE, int NS>
 __global__ void __launch_bounds__(512, 2)
 mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, const char* __restrict__ Q8, const f32x4* __restrict__ qab, int nq, int q_base,
-                     unsigned* __restrict__ gmax, u64* __restrict__ cand, int* __restrict__ cand_cnt, int* __restrict__ overflow) {
+                     unsigned* __restrict__ gmax, u64* __restrict__ cand, int* __restrict__ cand_cnt, int* __restrict__ overflow, u64* __restrict__ gstar) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SB_BYTES = 2 * NKB8 * kFragBytes + kI8Tail;
     constexpr int SPS = 2;                   // super-blocks per stage: ONE barrier and one burst of DMA issue per 64 rows
@@ -1715,6 +1724,7 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
     asm volatile("" : "+v"(qt), "+v"(qa), "+v"(qb), "+v"(known));
     const f32x2 qt2 = {qt, qt}, qa2 = {qa, qa}, qb2 = {qb, qb};
     float lmax = -FLT_MAX;
+    unsigned lrow = 0;  // the row lmax belongs to (see mips_screen8_kernel)
     int my_cnt = 0;
     u64* my_list = cand + ((size_t)b * 8 + wave) * kWaveCandCap;
     const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -1760,14 +1770,21 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
         const unsigned row0 = (unsigned)R.sb * 32u + 4u * (unsigned)lh;
         const bool whole = (long long)R.sb * 32 + 32 <= n_rows;  // wave-uniform
         if (whole && (MODE != 1 || __ballot(q_valid && mu >= known) == 0ull)) {
-            if (q_valid) lmax = fmaxf(lmax, mu - 2.f * fmaf(qa, smax, qb));
+            const float cl = mu - 2.f * fmaf(qa, smax, qb);
+            if (q_valid && cl > lmax) {  // a new record for this lane: remember the row
+                lmax = cl;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (u2[r >> 1][r & 1] == mu) lrow = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float up = u2[r >> 1][r & 1];
                 const unsigned row = row0 + (unsigned)((r & 3) + 8 * (r >> 2));
                 const bool ok = (long long)row < n_rows && q_valid;
-                if (ok) lmax = fmaxf(lmax, up - 2.f * fmaf(qa, R.sr[r >> 2][r & 3], qb));
+                const float lr_ = up - 2.f * fmaf(qa, R.sr[r >> 2][r & 3], qb);
+                if (ok && lr_ > lmax) { lmax = lr_; lrow = row; }
                 if (MODE == 1) {
                     const bool hit = ok && up >= known;
                     const u64 m = __ballot(hit);
@@ -1859,6 +1876,7 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
     {
         const float hm = fmaxf(lmax, __shfl_xor(lmax, 32));
         if (lane < 32 && q_valid && hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
+        if (q_valid && lmax == hm && hm > -FLT_MAX) atomicMax(gstar + qlocal, ((u64)ord32(lmax) << 32) | lrow);
     }
     if (MODE == 1 && lane == 0) {
         cand_cnt[b * 8 + wave] = my_cnt < kWaveCandCap ? my_cnt : kWaveCandCap;
@@ -1870,6 +1888,20 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
 // exact re-scoring of the int8 tier's candidates: as mips_refine_kernel, after dropping every candidate whose (rounded-up) upper
 // bound lies below the FINAL largest lower bound of its query -- most of a no-clear-winner query's candidates were emitted early,
 // against a `known` that the pass later raised. ctl8[1] counts the candidates that are really re-scored.
+// The row with the best lower bound of every query is re-scored FIRST: its exact score seeds the thresholds of mips_refine8_kernel,
+// which then only gathers the rows whose upper bound reaches an exact score (a handful per query instead of hundreds).
+__global__ void __launch_bounds__(256)
+mips_star8_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, const u64* __restrict__ gstar, int nq,
+                  u64* __restrict__ best) {
+    const int qi = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (qi >= nq) return;
+    const u64 key = gstar[qi];
+    if (key == 0) return;
+    const unsigned row = (unsigned)key;
+    const float acc = exact_dot16<false>(Xhi, Xlo, nkb, q + (size_t)qi * (nkb * 32), row, sub);
+    if (sub == 0) atomicMax(best + qi, make_key(acc, row));
+}
+
 // `limit`: emitted candidates (ctl8[3], summed by the main pass) beyond which filtering and re-scoring them would cost more than the
 // fp16 screen pass behind this tier (data for which the int8 bound is loose: rows with a large common mean, all-ties corpora):
 // the tier then declares itself overflowed.
@@ -2184,7 +2216,7 @@ struct SearchPlan {
     int G8w;  // workgroups of its 32-queries-per-wave kernel
     int G8;   // its workgroups: TWO per CU (24.25 KiB super-blocks: three slots are 73 KiB), one's barrier and epilogue under the other's MFMAs.
               // Measured at 5 M rows, planted queries, whole call: 1 per CU 1.013 ms, 1 per CU with 64-row stages 0.995 ms, 2 per CU 0.907 ms.
-    size_t off_q8, off_qab, off_ctl8;
+    size_t off_q8, off_qab, off_ctl8, off_gstar;
 };
 
 #ifndef MDR_I8W_SLOTS
@@ -2250,6 +2282,7 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     p.off_q8 = take(p.i8 ? nq_pad * h->d : 0);
     p.off_qab = take(p.i8 ? nq_pad * 16 : 0);
     p.off_ctl8 = take(p.i8 ? 256 : 0);  // [0] a candidate list of the int8 tier overflowed -> the fp16 screen runs
+    p.off_gstar = take(p.i8 ? nq_pad * 8 : 0);
     p.total = o + 256;
     return p;
 }
@@ -2323,13 +2356,16 @@ int run_screen8(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
     f32x4* qab = (f32x4*)(ws + p.off_qab);
     const int nq_pad = kStreamQ;
     const int n_sb = (int)((h->ntotal + 31) / 32);
+    u64* gstar = (u64*)(ws + p.off_gstar);
     MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
+    MDR_HIP_TRY(hipMemsetAsync(gstar, 0, (size_t)nq_pad * 8, st));
     MDR_HIP_TRY(hipMemsetAsync(ctl8, 0, 256, st));
     hipLaunchKernelGGL(prep_queries_i8_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)(h->flags + 8), q8, qab);
     hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 0, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
-                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8);
+                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar);
     hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 1, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
-                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8);
+                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar);
+    hipLaunchKernelGGL(mips_star8_kernel, dim3((nq + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)gstar, nq, best);
     hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8 * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
                        (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nq);
     MDR_HIP_TRY(hipGetLastError());
@@ -2386,7 +2422,9 @@ int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
     const int ngroups = (nq + kWideQ - 1) / kWideQ;
     const int nq_pad = ngroups * kWideQ;
     const int n_sb = (int)((h->ntotal + 31) / 32);
+    u64* gstar = (u64*)(ws + p.off_gstar);
     MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
+    MDR_HIP_TRY(hipMemsetAsync(gstar, 0, (size_t)nq_pad * 8, st));
     MDR_HIP_TRY(hipMemsetAsync(ctl8, 0, 256, st));
     hipLaunchKernelGGL(prep_queries_i8_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)(h->flags + 8), q8, qab);
     for (int gi = 0; gi < ngroups; ++gi) {
@@ -2394,9 +2432,11 @@ int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
         const char* qg = q8 + (size_t)gi * kWideQ * h->d;
         if (gi) MDR_HIP_TRY(hipMemsetAsync(ctl8 + 3, 0, sizeof(int), st));  // emitted-candidate total of this group's pass
         hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 0, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
-                           (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8);
+                           (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8, gstar + (size_t)gi * kWideQ);
         hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 1, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
-                           (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8);
+                           (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8, gstar + (size_t)gi * kWideQ);
+        hipLaunchKernelGGL(mips_star8_kernel, dim3((nqg + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb,
+                           q_dev + (size_t)gi * kWideQ * h->d, (const u64*)(gstar + (size_t)gi * kWideQ), nqg, best + (size_t)gi * kWideQ);
         hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8w * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
                            (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nqg);
         MDR_HIP_TRY(hipGetLastError());
