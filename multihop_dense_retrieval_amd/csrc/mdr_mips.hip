@@ -1454,7 +1454,8 @@ template <int NKB8, int MODE, int NS>  // NS: LDS slots of one super-block (NS -
 __global__ void __launch_bounds__(512, 2)
 mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, const char* __restrict__ Q8, const f32x4* __restrict__ qab, int nq, int q_base,
                     unsigned* __restrict__ gmax /* [nq] ordered(max L) */, u64* __restrict__ cand /* [waves][kWaveCandCap] */,
-                    int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow, u64* __restrict__ gstar /* [nq] (ordered max L, its row) */) {
+                    int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow, u64* __restrict__ gstar /* [nq] (ordered max L, its row) */,
+                    const u64* __restrict__ best /* MODE 1: exact keys of the sample pass's star rows (a tighter first `known`) */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SB_BYTES = 2 * NKB8 * kFragBytes + kI8Tail;
     constexpr int CPW = NKB8 / 4;  // DMA pieces per wave and stage (wave 0: + 1, the scale tail)
@@ -1486,6 +1487,8 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
     if (MODE == 1 && q_valid) {
         unsigned g = gmax[qlocal];
         if (g) known = unord32(g);
+        const u64 kb = best[q_base + qlocal];  // the exact score of a real row is a lower bound of the best score too
+        if (kb) known = fmaxf(known, key_score(kb));
     }
     // retire every register load before the loop (see mips_screen_kernel)
 #pragma unroll
@@ -1678,7 +1681,8 @@ __device__ unsigned long long g_i8_stamp[8];
 template <int NKB8, int MODE, int NS>
 __global__ void __launch_bounds__(512, 2)
 mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, const char* __restrict__ Q8, const f32x4* __restrict__ qab, int nq, int q_base,
-                     unsigned* __restrict__ gmax, u64* __restrict__ cand, int* __restrict__ cand_cnt, int* __restrict__ overflow, u64* __restrict__ gstar) {
+                     unsigned* __restrict__ gmax, u64* __restrict__ cand, int* __restrict__ cand_cnt, int* __restrict__ overflow, u64* __restrict__ gstar,
+                     const u64* __restrict__ best) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SB_BYTES = 2 * NKB8 * kFragBytes + kI8Tail;
     constexpr int SPS = 2;                   // super-blocks per stage: ONE barrier and one burst of DMA issue per 64 rows
@@ -1718,6 +1722,8 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
     if (MODE == 1 && q_valid) {
         unsigned g = gmax[qlocal];
         if (g) known = unord32(g);
+        const u64 kb = best[q_base + qlocal];
+        if (kb) known = fmaxf(known, key_score(kb));
     }
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) asm volatile("" : "+v"(qf[sl]));
@@ -2362,9 +2368,11 @@ int run_screen8(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
     MDR_HIP_TRY(hipMemsetAsync(ctl8, 0, 256, st));
     hipLaunchKernelGGL(prep_queries_i8_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)(h->flags + 8), q8, qab);
     hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 0, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
-                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar);
+                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar, (const u64*)best);
+    // the sample pass's best-lower-bound rows, re-scored exactly: a first `known` that is up to 2 B tighter than their lower bounds
+    hipLaunchKernelGGL(mips_star8_kernel, dim3((nq + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)gstar, nq, best);
     hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 1, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
-                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar);
+                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar, (const u64*)best);
     hipLaunchKernelGGL(mips_star8_kernel, dim3((nq + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)gstar, nq, best);
     hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8 * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
                        (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nq);
@@ -2432,9 +2440,13 @@ int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
         const char* qg = q8 + (size_t)gi * kWideQ * h->d;
         if (gi) MDR_HIP_TRY(hipMemsetAsync(ctl8 + 3, 0, sizeof(int), st));  // emitted-candidate total of this group's pass
         hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 0, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
-                           (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8, gstar + (size_t)gi * kWideQ);
+                           (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8, gstar + (size_t)gi * kWideQ,
+                           (const u64*)best);
+        hipLaunchKernelGGL(mips_star8_kernel, dim3((nqg + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb,
+                           q_dev + (size_t)gi * kWideQ * h->d, (const u64*)(gstar + (size_t)gi * kWideQ), nqg, best + (size_t)gi * kWideQ);
         hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 1, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
-                           (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8, gstar + (size_t)gi * kWideQ);
+                           (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8, gstar + (size_t)gi * kWideQ,
+                           (const u64*)best);
         hipLaunchKernelGGL(mips_star8_kernel, dim3((nqg + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb,
                            q_dev + (size_t)gi * kWideQ * h->d, (const u64*)(gstar + (size_t)gi * kWideQ), nqg, best + (size_t)gi * kWideQ);
         hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8w * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
