@@ -13,7 +13,7 @@ for MODE in sequential pipelined; do
     N=$(echo $PMC | tr ' ' '_' | cut -c1-30)
     timeout 300 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/p -o p -- python $REPO/bench.py --rows 5000000 --steps 3 --warmup 1 --no-encoder --no-cpu-baseline --no-sequential --no-verify $FLAG > $OUT/log_${MODE}_$N.txt 2>&1
     P=$(find $OUT/p -name "*counter_collection.csv" | head -1)
-    if [ -n "$P" ]; then head -1 "$P" > $OUT/${MODE}_$N.csv; grep -E "mips_(screen|screen32|screen8|screen8w|refine|refine8)" "$P" >> $OUT/${MODE}_$N.csv; fi
+    if [ -n "$P" ]; then head -1 "$P" > $OUT/${MODE}_$N.csv; grep -E "mips_(screen|screen32|screen8|screen8w|refine|refine8|star8)" "$P" >> $OUT/${MODE}_$N.csv; fi
     rm -rf $OUT/p
   done
 done
@@ -24,7 +24,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/*_*.csv")):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         kern = ("screen8w" if "screen8w" in n else "screen8" if "screen8_kernel" in n else "screen32" if "screen32" in n
-                else "screen" if "mips_screen_kernel" in n else "count8" if "count8" in n else "refine8" if "refine8" in n else "refine")
+                else "screen" if "mips_screen_kernel" in n else "star8" if "star8" in n else "refine8" if "refine8" in n else "refine")
         mode = "main" if ("<24, 1" in n or "<12, 1" in n) else "sample" if ("<24, 0" in n or "<12, 0" in n) else ""
         dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         agg[(kern + " " + mode, r["Counter_Name"])].append((float(r["Counter_Value"]), dur))
