@@ -53,10 +53,10 @@ PMC_TRAFFIC_RATIO = {
     # 32 queries per wave: main 3.75258e6 KB + refine 52561 KB + sample 26145 KB, x2 -> 7.847e9 B per search (200 queries)
     "mips_screen32_kernel": (0.5109, "profiles/r02_mips5m_pmc_pipelined_FETCH_SIZE.csv"),
     "mips_stream_kernel": (1.001, "profiles/r01_mips1m_pmc_fetch_size.csv"),
-    # int8 screening tier (776 B per row), 16 queries per wave: main 1.89632e6 KB + sample 25252 + refine 2194 + count 838, x2 -> 3.942e9 B per search
-    "mips_screen8_kernel": (0.2566, "profiles/r02_mips5m_i8_pmc_sequential_FETCH_SIZE.csv"),
-    # 32 queries per wave: main 1.89725e6 KB + sample 25648 + refine 3473 + count 1034, x2 -> 3.947e9 B per search (200 queries)
-    "mips_screen8w_kernel": (0.2570, "profiles/r02_mips5m_i8_pmc_pipelined_FETCH_SIZE.csv"),
+    # int8 screening tier (776 B per row), 16 queries per wave: main 1.89632e6 KB + sample 25255 + refine 1955 + 2 x star 1364, x2 -> 3.945e9 B per search
+    "mips_screen8_kernel": (0.2568, "profiles/r02_mips5m_i8_pmc_sequential_FETCH_SIZE.csv"),
+    # 32 queries per wave: main 1.89644e6 KB + sample 25700 + refine 2929 + 2 x star 2447, x2 -> 3.953e9 B per search (200 queries)
+    "mips_screen8w_kernel": (0.2573, "profiles/r02_mips5m_i8_pmc_pipelined_FETCH_SIZE.csv"),
 }
 
 
