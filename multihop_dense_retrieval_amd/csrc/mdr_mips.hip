@@ -1464,7 +1464,10 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = gridDim.x, b = blockIdx.x;
     int n_it = (n_sb - b + G - 1) / G;  // >= 1 (grid <= n_sb)
-    if (MODE == 0 && n_it > kSampleStages) n_it = kSampleStages;
+    if (MODE == 0) {  // the sample pass scores 1/16 of the stages, at most kSampleStages (small shards: fewer)
+        const int samp = max(1, min(kSampleStages, n_it >> 4));
+        if (n_it > samp) n_it = samp;
+    }
 
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i)
@@ -1695,7 +1698,10 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
     const int G = gridDim.x, b = blockIdx.x;
     const int n_st = (n_sb + SPS - 1) / SPS;  // (the plane is allocated to a whole number of stages)
     int n_it = (n_st - b + G - 1) / G;
-    if (MODE == 0 && n_it > kSampleStages) n_it = kSampleStages;
+    if (MODE == 0) {  // the sample pass scores 1/16 of the stages, at most kSampleStages (small shards: fewer)
+        const int samp = max(1, min(kSampleStages, n_it >> 4));
+        if (n_it > samp) n_it = samp;
+    }
     auto issue_stage = [&](int stg, char* dst) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < SPS; ++h) issue_super_block8<NKB8>(X8, SPS * stg + h, dst + h * SB_BYTES, wave, lane);
