@@ -1038,6 +1038,9 @@ __global__ void __launch_bounds__(512) attention_kernel(const _Float16* __restri
 // 1 / sum is applied to the fp32 result.
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
+#ifndef MDR_ATTN_MERGE
+#define MDR_ATTN_MERGE 1
+#endif
 template <int NTC>  // key tiles of 16 per chunk
 __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
                                                                _Float16* __restrict__ ctx) {
@@ -1052,19 +1055,12 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
     const int start = cu[b], len = cu[b + 1] - start;
     const int qb0 = blockIdx.z * 128;
     if (qb0 >= len) return;
+    // A sequence whose keys fit ONE chunk (len <= KC) and that has two query blocks is served by its first workgroup alone: K and V
+    // are staged once and the second block of 128 queries runs over the same image (MDR_ATTN_MERGE=0 builds: one workgroup per block).
+    const bool merged = MDR_ATTN_MERGE && len <= KC && len > 128;
+    if (merged && blockIdx.z > 0) return;
+    const int nsub = merged ? 2 : 1;
     const int H3 = 3 * H;
-    const int q0 = qb0 + wave * 16;
-    const bool wave_valid = q0 < len;  // waves past the sequence only help staging
-    const int qi = q0 + lr;
-    const bool qvalid = qi < len;
-    const int qrow = qvalid ? qi : len - 1;
-    half8 qf[2];
-#pragma unroll
-    for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const half8*)(qkv + (size_t)(start + qrow) * H3 + h * 64 + ds * 32 + g * 8);
-    // retire the Q loads before any DMA is in flight (a pending register load would make the compiler drain the DMA later)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int ds = 0; ds < 2; ++ds) asm volatile("" : "+v"(qf[ds]));
 
     // DMA plan: wave-instruction i covers LDS slots 64 i .. 64 i + 63 = rows 8 i .. 8 i + 7; this lane: row 8 i + (lane >> 3),
     // slot lane & 7 holding source chunk (lane & 7) ^ (row & 7) = (lane & 7) ^ (lane >> 3)
@@ -1079,6 +1075,20 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) v_rd[dt] = vkey * 128 + ((((dt * 2 + ((lr & 3) >> 1)) ^ vsw)) << 4) + (lr & 1) * 8;
 
+    for (int sub = 0; sub < nsub; ++sub) {
+    const int q0 = qb0 + sub * 128 + wave * 16;
+    const bool wave_valid = q0 < len;  // waves past the sequence only help staging
+    const int qi = q0 + lr;
+    const bool qvalid = qi < len;
+    const int qrow = qvalid ? qi : len - 1;
+    half8 qf[2];
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const half8*)(qkv + (size_t)(start + qrow) * H3 + h * 64 + ds * 32 + g * 8);
+    // retire the Q loads before any DMA is in flight (a pending register load would make the compiler drain the DMA later)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) asm volatile("" : "+v"(qf[ds]));
+
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 o[4];
 #pragma unroll
@@ -1088,17 +1098,19 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
         const int ck = min(KC, len - kc0);     // keys of this chunk
         const int nt = (ck + 15) >> 4;
         const int np = (nt + 1) >> 1;
-        if (kc0 > 0) __syncthreads();          // every wave is done reading the previous chunk
-        // ---- stage K and V rows kc0 .. kc0 + 32 np - 1 (clamped to len - 1)
-        for (int i = wave; i < np * 4; i += 8) {
-            int row = kc0 + i * 8 + st_row;
-            row = row < len ? row : len - 1;
-            const _Float16* src = qkv + (size_t)(start + row) * H3 + H + h * 64 + st_col;
-            __builtin_amdgcn_global_load_lds(MDR_GPTR(src), MDR_LPTR(Ks + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(MDR_GPTR(src + H), MDR_LPTR(Vs + i * 1024), 16, 0, 0);
+        if (sub == 0) {                        // (the second block of a merged pair finds its single chunk staged)
+            if (kc0 > 0) __syncthreads();      // every wave is done reading the previous chunk
+            // ---- stage K and V rows kc0 .. kc0 + 32 np - 1 (clamped to len - 1)
+            for (int i = wave; i < np * 4; i += 8) {
+                int row = kc0 + i * 8 + st_row;
+                row = row < len ? row : len - 1;
+                const _Float16* src = qkv + (size_t)(start + row) * H3 + H + h * 64 + st_col;
+                __builtin_amdgcn_global_load_lds(MDR_GPTR(src), MDR_LPTR(Ks + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(MDR_GPTR(src + H), MDR_LPTR(Vs + i * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         if (!wave_valid) continue;
 
         // ---- S^T tiles of this chunk: lane holds keys kc0 + 16 t + 4 g + r for query lr
@@ -1179,6 +1191,7 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
             *(half4*)(ctx + (size_t)(start + qi) * H + h * 64 + dt * 16 + 4 * g) = w;
         }
     }
+    }  // sub
 }
 
 // Last layer: only the CLS row of each sequence feeds the projection head, so its attention needs ONE query per
