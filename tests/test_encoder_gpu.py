@@ -141,3 +141,25 @@ def test_large_batch_kernels_agree_with_small_batch_path(models):
     print(f"large-batch vs small-batch path: max {err.max().item():.3e} mean {err.mean().item():.3e}")
     assert bool(torch.isfinite(big).all())
     assert err.max().item() <= 1e-6
+
+
+def test_attention_query_block_boundaries(models):
+    """Sequence lengths around the attention kernel's block structure -- 128 / 129 (one vs two query blocks), 200, 256 (two blocks served
+    by ONE workgroup that stages K/V once), 257, 300 (two key chunks, three blocks) -- against the numpy restatement of the reference
+    forward (oracle/roberta_oracle.py, fp64) on the 2-layer geometry."""
+    m, sd = models["tiny"]
+    geom = seeded.TINY
+    lens = [128, 129, 130, 200, 255, 256, 257, 300, 16, 2]
+    L = 300
+    rng = np.random.RandomState(5)
+    ids = np.full((len(lens), L), 1, np.int64)
+    mask = np.zeros((len(lens), L), np.int64)
+    for b, n in enumerate(lens):
+        ids[b, :n] = rng.randint(3, geom["vocab"], n)
+        ids[b, 0], ids[b, n - 1] = 0, 2
+        mask[b, :n] = 1
+    out = m.encode_q(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda(), None).cpu().numpy()
+    ref = roberta_oracle.encode(sd, geom, ids, mask, np.float64)
+    err = np.abs(out - ref)
+    print("attention block boundaries: max abs err per length", dict(zip(lens, np.round(err.max(1), 5))))
+    assert err.max() <= TOL["tiny"][0] and err.mean() <= TOL["tiny"][1]
