@@ -1014,6 +1014,7 @@ __global__ void __launch_bounds__(512) attention_kernel(const _Float16* __restri
                 }
             }
         if (qvalid) {
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));  // (see attention_stream_kernel's epilogue)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 half4 w;
@@ -1040,6 +1041,11 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 #ifndef MDR_ATTN_MERGE
 #define MDR_ATTN_MERGE 1
+#endif
+// measurement builds (wrong results; scripts/gpu_attn_ab.sh): 1 no K fragment reads, 2 no V fragment reads, 3 neither, 4 staging only
+// (Q loads, K/V DMA, barrier, context stores), 5 no exp, 6 = 4 with K only, 7 = 4 without the stores, 8 = 4 with one row per DMA piece
+#ifndef MDR_ATTN_ABL
+#define MDR_ATTN_ABL 0
 #endif
 template <int NTC>  // key tiles of 16 per chunk
 __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
@@ -1102,15 +1108,16 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
             if (kc0 > 0) __syncthreads();      // every wave is done reading the previous chunk
             // ---- stage K and V rows kc0 .. kc0 + 32 np - 1 (clamped to len - 1)
             for (int i = wave; i < np * 4; i += 8) {
-                int row = kc0 + i * 8 + st_row;
+                int row = kc0 + i * 8 + (MDR_ATTN_ABL == 8 ? 0 : st_row);
                 row = row < len ? row : len - 1;
                 const _Float16* src = qkv + (size_t)(start + row) * H3 + H + h * 64 + st_col;
                 __builtin_amdgcn_global_load_lds(MDR_GPTR(src), MDR_LPTR(Ks + i * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(MDR_GPTR(src + H), MDR_LPTR(Vs + i * 1024), 16, 0, 0);
+                if (MDR_ATTN_ABL != 6) __builtin_amdgcn_global_load_lds(MDR_GPTR(src + H), MDR_LPTR(Vs + i * 1024), 16, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        if (MDR_ATTN_ABL == 4 || MDR_ATTN_ABL >= 6) continue;
         if (!wave_valid) continue;
 
         // ---- S^T tiles of this chunk: lane holds keys kc0 + 16 t + 4 g + r for query lr
@@ -1120,8 +1127,12 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
         for (int t = 0; t < NTC; ++t) {
             s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             if (t < nt) {
-                const half8 k0 = *(const half8*)(Ks + k_rd + t * 2048 + ksw0);
-                const half8 k1 = *(const half8*)(Ks + k_rd + t * 2048 + ksw1);
+                half8 k0, k1;
+                if (MDR_ATTN_ABL == 1 || MDR_ATTN_ABL == 3) { k0 = qf[1]; k1 = qf[0]; }
+                else {
+                    k0 = *(const half8*)(Ks + k_rd + t * 2048 + ksw0);
+                    k1 = *(const half8*)(Ks + k_rd + t * 2048 + ksw1);
+                }
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], acc, 0, 0, 0);
@@ -1147,7 +1158,8 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
             if (t < nt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], 1.4426950408889634f, mb));  // argument <= 0 (up to rounding): raw v_exp_f32
+                    const float e = MDR_ATTN_ABL == 5 ? fmaf(s[t][r], 1.4426950408889634f, mb)
+                                                      : __builtin_amdgcn_exp2f(fmaf(s[t][r], 1.4426950408889634f, mb));  // argument <= 0 (up to rounding): raw v_exp_f32
                     s[t][r] = e;
                     csum += e;
                 }
@@ -1172,6 +1184,7 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
                 }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
+                    if (MDR_ATTN_ABL == 2 || MDR_ATTN_ABL == 3) { o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[dt & 1], pf, o[dt], 0, 0, 0); continue; }
                     const char* vp = Vs + pt * 4096 + v_rd[dt];
                     const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)vp);
                     const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vp + 2048));
@@ -1181,7 +1194,11 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
                 }
             }
     }
-    if (qvalid) {
+    if (qvalid && MDR_ATTN_ABL != 7) {
+        // The last PV MFMAs sit behind per-pair branches, and hipcc's hazard recogniser does not look across a branch for the
+        // distance a VALU read of an MFMA result needs (found with a variant of this kernel that consumed S tiles right behind a
+        // per-tile branch: NaNs, gone with the nops). Nothing has ever been wrong here; the 16 wait states are insurance.
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
         const float inv = 1.f / l_run;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
