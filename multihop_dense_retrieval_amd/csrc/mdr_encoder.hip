@@ -1394,6 +1394,14 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
     const long long mid_blocks = (long long)(N / 128) * ((M_est + 127) / 128);
     const long long small_blocks = (long long)(N / 64) * ((M_est + 63) / 64);
     if (sel == 3 && big_blocks > 0) return launch_gemm_cfg<EPI, GemmBig>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
+#ifdef MDR_GEMM_EXTRA_CFGS  // measurement builds: more tile shapes behind the test hook's kernel ids 8-11
+    if (sel == 8) return launch_gemm_cfg<EPI, GemmCfg<128, 64, 2, 2, 3>>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
+    if (sel == 9) return launch_gemm_cfg<EPI, GemmCfg<64, 128, 2, 2, 3>>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
+    if (sel == 10) return launch_gemm_cfg<EPI, GemmCfg<128, 128, 2, 2, 3>>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
+    if (sel == 11) return launch_gemm_cfg<EPI, GemmCfg<64, 64, 2, 2, 4>>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
+    if (sel == 12) return launch_gemm_cfg<EPI, GemmCfg<128, 64, 4, 2, 3>>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
+    if (sel == 13) return launch_gemm_cfg<EPI, GemmCfg<64, 64, 4, 2, 3>>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, res, ldr, st);
+#endif
     // bytes the busiest CU pulls through its L2 path: rounds of blocks x (BM + BN) rows of K; ties go to the small tile
     // (measured at 2.4 k rows: QKV / FFN1 faster on 128x128, out-projection / FFN2 on 64x64)
     const long long c_mid = (mid_blocks + num_cus - 1) / num_cus * 256, c_small = (small_blocks + num_cus - 1) / num_cus * 128;
@@ -1544,7 +1552,11 @@ int mdr_test_gemm_f16(const void* A_dev, const void* W_dev, const float* bias_de
     MDR_REQUIRE(A_dev && W_dev && bias_dev && out_dev, "NULL pointer");
     MDR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "bad GEMM shape M=%d N=%d K=%d (N, K multiples of 64)", M, N, K);
     MDR_REQUIRE(epilogue == EPI_BIAS_F16 || epilogue == EPI_BIAS_GELU_F16 || epilogue == EPI_BIAS_F32, "epilogue must be 0, 1 or 3");
+#ifdef MDR_GEMM_EXTRA_CFGS
+    MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 6 || (kernel >= 8 && kernel <= 13), "kernel must be 0, 1, 2, 4, 6 or 8-13");
+#else
     MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 6, "kernel must be 0, 1, 2, 4 or 6");
+#endif
     DeviceGuard guard(device);
     if (!guard.ok) return set_error(MDR_E_HIP, "hipSetDevice(%d) failed", device);
     hipDeviceProp_t prop;
