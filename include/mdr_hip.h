@@ -190,13 +190,10 @@ int mdr_assemble_hop2(const int64_t* q_ids_dev, const int64_t* q_mask_dev, int b
  * ---------------------------------------------------------------------------------------------- */
 int mdr_test_gemm_f16(const void* A_dev, const void* W_dev, const float* bias_dev, int M, const int* m_dev, int N, int K,
                       void* out_dev, int epilogue, int kernel, int device, void* stream);
-/* Measurement hook: the s_memtime timeline the persistent 256x256 GEMM accumulates when it is launched with the environment
- * knob MDR_GEMM_ABL=5 (shader cycles of wave 0 summed over workgroups: [0] wait + barrier A, [1..3] sub-phases 1-3,
- * [4] wait + barrier B, [5] sub-phase 4, [6] epilogue, [7] K-tiles counted); synchronises the device; reset != 0 clears it. */
-int mdr_test_gemm_stamps(unsigned long long* out8_host, int reset);
-/* Measurement hook: the same kind of timeline for the 32-queries-per-wave int8 screen kernel, filled only by a library built with
- * -DMDR_I8_ABL=9 ([0] wait + barrier, [1] exchange + DMA issue, [2] MFMA chain, [3] epilogue, [4] bound sharing, [7] stages). */
-int mdr_test_i8_stamps(unsigned long long* out8_host, int reset);
+/* Measurement hooks that exist only in VARIANT builds of these sources (never in the product library) are declared in
+ * include/mdr_hip_measure.h. No environment variable changes what any entry point above computes: MDR_GEMM_CFG, MDR_MIPS_WIDE and
+ * MDR_MIPS_I8 only choose between kernels that return the same bits / the same exact results (tests/test_capi_symbols.py keeps
+ * the list of getenv() names in csrc/ closed). */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,30 @@
+/*
+ * include/mdr_hip_measure.h -- hooks of MEASUREMENT builds of libmdrhip (variant libraries built next to the product one with
+ *     python -m multihop_dense_retrieval_amd.build -DMDR_GEMM_ABL=5 --out=libmdrhip_gemm_timeline.so
+ *     python -m multihop_dense_retrieval_amd.build -DMDR_I8_ABL=9  --out=libmdrhip_i8_timeline.so
+ * and loaded by the measurement scripts through MDR_LIB_PATH). The product library (no -D) exports none of these, holds no
+ * timeline globals and none of the ablation code paths: every MDR_*_ABL switch is a compile-time macro, because several of them
+ * produce WRONG results by design (they remove one pipe's work to see what a kernel waits for).
+ *
+ * Replaces nothing in the reference (which has no native code); listed here so that the C ABI in mdr_hip.h stays the drop-in
+ * surface only.
+ */
+#ifndef MDR_HIP_MEASURE_H
+#define MDR_HIP_MEASURE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* -DMDR_GEMM_ABL=5 builds: the s_memtime timeline the persistent 256x256 GEMM accumulates (shader cycles of wave 0 summed over
+ * workgroups: [0] wait + barrier A, [1..3] sub-phases 1-3, [4] wait + barrier B, [5] sub-phase 4, [6] epilogue, [7] K-tiles counted);
+ * synchronises the device; reset != 0 clears it. Results of that build are correct. (scripts/gpu_gemm_bench.py) */
+int mdr_test_gemm_stamps(unsigned long long* out8_host, int reset);
+
+/* -DMDR_I8_ABL=9 builds: the same kind of timeline for the 32-queries-per-wave int8 screen kernel ([0] wait + barrier,
+ * [1] exchange + DMA issue, [2] MFMA chain, [3] epilogue, [4] bound sharing, [7] stages). (scripts/gpu_i8_quick.py) */
+int mdr_test_i8_stamps(unsigned long long* out8_host, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDR_HIP_MEASURE_H */

@@ -62,6 +62,9 @@ _SIGNATURES = {
     "mdr_encoder_set_fill_hint": (_c.c_int, [_c.c_void_p, _c.c_float]),
     "mdr_test_gemm_f16": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int,
                                      _c.c_int, _c.c_int, _c.c_void_p]),
+}
+# include/mdr_hip_measure.h: exported by measurement builds only (MDR_LIB_PATH=...); bound when present, absent from the product library
+_MEASURE_SIGNATURES = {
     "mdr_test_gemm_stamps": (_c.c_int, [_c.POINTER(_c.c_uint64), _c.c_int]),
     "mdr_test_i8_stamps": (_c.c_int, [_c.POINTER(_c.c_uint64), _c.c_int]),
 }
@@ -80,6 +83,10 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree
             fn.restype, fn.argtypes = res, args
+        for name, (res, args) in _MEASURE_SIGNATURES.items():
+            fn = getattr(L, name, None)
+            if fn is not None:
+                fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
 

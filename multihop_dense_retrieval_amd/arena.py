@@ -26,8 +26,11 @@ class TokenArena:
     # -- builders ----------------------------------------------------------------------------------------
     @classmethod
     def from_corpus(cls, id2doc, tokenizer, roberta=True, max_tokens=None):
-        """id2doc: {"<row id>": {"title","text"}} (mhop.load_corpus_dict). Passages are tokenised WITHOUT special tokens;
+        """id2doc: {"<row id>": {"title","text"}} (mhop.load_corpus_dict). Passages are tokenised WITHOUT special tokens, as the
+        second segment of transformers 2.11's pair encoding sees them (data.prefix_space_2_11: a leading space for RoBERTa);
         an empty text falls back to the title and is flagged (eval_mhop_retrieval.py:162-165)."""
+        from .data import is_roberta_family, prefix_space_2_11
+        pre = prefix_space_2_11 if is_roberta_family(tokenizer) else (lambda t: t)
         n = len(id2doc)
         toks, offs, empty = [], np.zeros(n + 1, np.int64), np.zeros(n, np.uint8)
         for i in range(n):
@@ -36,7 +39,7 @@ class TokenArena:
             if roberta and text.strip() == "":
                 text = doc["title"]
                 empty[i] = 1
-            ids = tokenizer(text, add_special_tokens=False)["input_ids"]
+            ids = tokenizer(pre(text), add_special_tokens=False)["input_ids"]
             if max_tokens is not None:
                 ids = ids[:max_tokens]  # never more than max_q_sp_len - 4 tokens can survive truncation
             toks.append(np.asarray(ids, np.int32))

@@ -7,6 +7,7 @@
 #include <cstdio>
 
 #include "../../include/mdr_hip.h"
+#include "../../include/mdr_hip_measure.h"
 
 namespace mdr {
 

@@ -435,6 +435,9 @@ gemm_f16_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
 // enough), 256x256 with four K=32 slots 7.4 ms (twice the barriers), burst-issued DMA +2 %, n-fastest tile order +9 %.
 // The residual of EPI_BIAS_RES_F32 is NOT added here: the LayerNorm kernel that follows adds it (res argument).
 using GemmP = GemmCfg<256, 128, 4, 2, 3>;   // 3 slots of 48 KiB: two batches in flight
+#ifndef MDR_GEMM_EPI
+#define MDR_GEMM_EPI 2
+#endif
 constexpr int kPersistBiasMax = 3072;  // floats of bias kept in LDS behind the ring (12 KiB)
 
 template <int EPI, typename C>
@@ -668,13 +671,19 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
 // its MFMAs whichever of DMA / MFMA / LDS reads was removed -- the barrier skeleton itself; removed.
 using GemmB2 = GemmCfg<256, 256, 2, 4, 2>;
 
-// ABL (measurement only, results are wrong for ABL != 0 except 5): 1 = no DMA after the prologue, 2 = no LDS fragment reads, 3 = no MFMAs,
-// 4 = no epilogue stores -- which of the CU's pipes the K-loop is waiting for (scripts/gpu_gemm_bench.py, MDR_GEMM_ABL).
-// 5 = correct results + an s_memtime timeline of wave 0 of every workgroup summed into g_gemm_stamp (mdr_test_gemm_stamps):
-// [0] wait + barrier A, [1] sub-phase 1 (incl. its fragment reads), [2] sub-phase 2, [3] sub-phase 3, [4] wait + barrier B,
-// [5] sub-phase 4, [6] epilogue, [7] K-tiles counted.
+// ABL = the COMPILE-TIME macro MDR_GEMM_ABL of a measurement build (`build.py -DMDR_GEMM_ABL=n --out=libmdrhip_abl.so`, selected with
+// MDR_LIB_PATH by scripts/gpu_gemm_bench.py); the product library is built with 0 and holds none of this. Results are wrong for
+// ABL != 0 except 5: 1 = no DMA after the prologue, 2 = no LDS fragment reads, 3 = no MFMAs, 4 = no epilogue stores -- which of the
+// CU's pipes the K-loop is waiting for. 5 = correct results + an s_memtime timeline of wave 0 of every workgroup summed into
+// g_gemm_stamp (mdr_test_gemm_stamps, include/mdr_hip_measure.h): [0] wait + barrier A, [1] sub-phase 1 (incl. its fragment reads),
+// [2] sub-phase 2, [3] sub-phase 3, [4] wait + barrier B, [5] sub-phase 4, [6] epilogue, [7] K-tiles counted.
+#ifndef MDR_GEMM_ABL
+#define MDR_GEMM_ABL 0
+#endif
+#if MDR_GEMM_ABL == 5
 __device__ unsigned long long g_gemm_stamp[8];
-template <int EPI, int ABL = 0>
+#endif
+template <int EPI, int ABL = MDR_GEMM_ABL>
 __global__ void __launch_bounds__(512)
 gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M_cap,
                 const int* __restrict__ M_dev, int N, int K, void* __restrict__ out, int ldo) {
@@ -881,14 +890,14 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus pieces must have landed before the LDS is released
-    if (ABL == 5) {
-        stamp(6);
-        if (tid == 0) {
+#if MDR_GEMM_ABL == 5
+    stamp(6);
+    if (tid == 0) {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) atomicAdd(&g_gemm_stamp[i], stamp_sum[i]);
-            atomicAdd(&g_gemm_stamp[7], (unsigned long long)total);
-        }
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_gemm_stamp[i], stamp_sum[i]);
+        atomicAdd(&g_gemm_stamp[7], (unsigned long long)total);
     }
+#endif
 }
 
 using GemmBig = GemmCfg<256, 256, 4, 2, 2>;
@@ -1041,6 +1050,9 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 #ifndef MDR_ATTN_MERGE
 #define MDR_ATTN_MERGE 1
+#endif
+#ifndef MDR_ATTN_FORCE
+#define MDR_ATTN_FORCE 0
 #endif
 // measurement builds (wrong results; scripts/gpu_attn_ab.sh): 1 no K fragment reads, 2 no V fragment reads, 3 neither, 4 staging only
 // (Q loads, K/V DMA, barrier, context stores), 5 no exp, 6 = 4 with K only, 7 = 4 without the stores, 8 = 4 with one row per DMA piece
@@ -1336,9 +1348,9 @@ int launch_gemm_persist(const _Float16* A, int lda, const _Float16* W, const flo
     constexpr int lds = C::LDS_BYTES + kPersistBiasMax * 4;
     { int rc_ = ensure_dynamic_lds((const void*)gemm_persist_kernel<EPI, C>, lds); if (rc_) return rc_; }
     const int grid = num_cus / 8 * 8;
-    const char* em = getenv("MDR_GEMM_EPI");  // measurement knob: 0 stores after the tile, 1 deferred, 2 deferred + two stores may stay in flight
+    // MDR_GEMM_EPI (compile-time, measurement builds): 0 stores after the tile, 1 deferred, 2 (product) deferred + two stores may stay in flight
     hipLaunchKernelGGL((gemm_persist_kernel<EPI, C>), dim3(grid), dim3(C::THREADS), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo,
-                       em ? atoi(em) : 2);
+                       MDR_GEMM_EPI);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }
@@ -1348,17 +1360,6 @@ int launch_gemm_big(const _Float16* A, int lda, const _Float16* W, const float* 
                     int M_est, int num_cus, hipStream_t st) {
     constexpr int lds = GemmB2::LDS_BYTES + kPersistBiasMax * 4 + 8 * 2048;  // slots + bias + per-wave epilogue scratch
     const int grid = num_cus / 8 * 8;
-    const char* abl_env = getenv("MDR_GEMM_ABL");  // measurement knob (wrong results): see gemm_big_kernel
-    const int abl = abl_env ? atoi(abl_env) : 0;
-#define MDR_BIG_ABL(A_)                                                                                                          \
-    if (abl == A_) {                                                                                                              \
-        { int rc_ = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI, A_>, lds); if (rc_) return rc_; }                         \
-        hipLaunchKernelGGL((gemm_big_kernel<EPI, A_>), dim3(grid), dim3(512), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo); \
-        MDR_HIP_TRY(hipGetLastError());                                                                                           \
-        return MDR_OK;                                                                                                            \
-    }
-    MDR_BIG_ABL(1) MDR_BIG_ABL(2) MDR_BIG_ABL(3) MDR_BIG_ABL(4) MDR_BIG_ABL(5)
-#undef MDR_BIG_ABL
     { int rc_ = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI>, lds); if (rc_) return rc_; }
     hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(grid), dim3(512), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo);
     MDR_HIP_TRY(hipGetLastError());
@@ -1570,6 +1571,7 @@ int mdr_test_gemm_f16(const void* A_dev, const void* W_dev, const float* bias_de
     return launch_gemm<EPI_BIAS_F32>(A, K, W, bias_dev, M, m_dev, N, K, out_dev, N, nullptr, 0, M, ncu, st, nullptr, kernel);
 }
 
+#if MDR_GEMM_ABL == 5  // measurement builds only (include/mdr_hip_measure.h)
 int mdr_test_gemm_stamps(unsigned long long* out8_host, int reset) {
     MDR_REQUIRE(out8_host, "NULL pointer");
     MDR_HIP_TRY(hipDeviceSynchronize());
@@ -1580,6 +1582,7 @@ int mdr_test_gemm_stamps(unsigned long long* out8_host, int reset) {
     }
     return MDR_OK;
 }
+#endif
 
 int mdr_encoder_set_fill_hint(mdr_encoder* h, float fill) {
     MDR_REQUIRE(h != nullptr, "encoder handle is NULL");
@@ -1667,7 +1670,7 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
             MDR_HIP_TRY(hipGetLastError());
             break;
         }
-        static const int attn_sel = getenv("MDR_ATTN") ? atoi(getenv("MDR_ATTN")) : 0;  // experiment knob: 1 = one-shot kernel, 2 = streaming kernel
+        constexpr int attn_sel = MDR_ATTN_FORCE;  // compile-time (measurement builds): 1 = one-shot kernel, 2 = streaming kernel, 0 (product) = by length
         if (attn_sel == 2 || (attn_sel == 0 && L > 128)) {
             rc = L <= 64 ? launch_attention_stream<4>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st)
                          : launch_attention_stream<16>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);

@@ -1679,7 +1679,9 @@ __device__ __forceinline__ i32x16 mfma_chain8x32(const char* p, const i32x4 (&qf
 
 // MDR_I8_ABL=9 builds: s_memtime timeline of wave 0 of every workgroup of the MODE 1 wide kernel, summed:
 // [0] wait + barrier, [1] exchange + DMA issue, [2] scale reads + MFMA chain, [3] epilogue (incl. bound sharing), [7] stages
+#if MDR_I8_ABL == 9
 __device__ unsigned long long g_i8_stamp[8];
+#endif
 
 template <int NKB8, int MODE, int NS>
 __global__ void __launch_bounds__(512, 2)
@@ -1880,11 +1882,13 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
                 decide(P[h]);
             }
     }
-    if (MDR_I8_ABL == 9 && MODE == 1 && threadIdx.x == 0) {
+#if MDR_I8_ABL == 9
+    if (MODE == 1 && threadIdx.x == 0) {
 #pragma unroll
         for (int e = 0; e < 5; ++e) atomicAdd(&g_i8_stamp[e], st_sum[e]);
         atomicAdd(&g_i8_stamp[7], (unsigned long long)n_it);
     }
+#endif
     {
         const float hm = fmaxf(lmax, __shfl_xor(lmax, 32));
         if (lane < 32 && q_valid && hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
@@ -2238,7 +2242,11 @@ struct SearchPlan {
 #define MDR_I8_SLOTS 3  // variant-build knob: LDS ring depth of the int8 screen kernels (3: two workgroups per CU, 4-6: one)
 #endif
 // variant 4 = the screen path WITHOUT the int8 tier (tests and A/B runs)
-bool i8_tier(const mdr_index* h, int path, int nq, int k) { return h->i8 != nullptr && h->variant != 4 && path == PATH_SCREEN && k == 1 && nq < 65536; }
+// (run_screen8 serves ONE group of at most kStreamQ queries; more than that goes to the 32-queries-per-wave kernel, which loops over
+// groups of 256 -- or, with MDR_MIPS_WIDE=0, stays on the fp16 screen, which loops over groups of 128)
+bool i8_tier(const mdr_index* h, int path, int nq, int k) {
+    return h->i8 != nullptr && h->variant != 4 && path == PATH_SCREEN && k == 1 && nq < 65536 && (nq <= kStreamQ || wide_pass(nq));
+}
 
 SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     SearchPlan p{};
@@ -2603,7 +2611,7 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
     hipStream_t st = (hipStream_t)stream;
     int rc = grow(h, h->ntotal + n, st);
     if (rc) return rc;
-    int before[4] = {0, 0, 0, 0};
+    int before[16] = {0};  // [0..3] range / query / norm flags, [8..9] the int8 tier's row statistics: all restored when the rows are rejected
     MDR_HIP_TRY(hipMemcpyAsync(before, h->flags, sizeof(before), hipMemcpyDeviceToHost, st));
     MDR_HIP_TRY(hipStreamSynchronize(st));
     const size_t row_src = (size_t)h->d * elem_size(src_dtype);
@@ -2810,6 +2818,7 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
     return MDR_OK;
 }
 
+#if MDR_I8_ABL == 9  // measurement builds only (include/mdr_hip_measure.h)
 int mdr_test_i8_stamps(unsigned long long* out8_host, int reset) {
     MDR_REQUIRE(out8_host, "NULL pointer");
     MDR_HIP_TRY(hipDeviceSynchronize());
@@ -2820,6 +2829,7 @@ int mdr_test_i8_stamps(unsigned long long* out8_host, int reset) {
     }
     return MDR_OK;
 }
+#endif
 
 int mdr_index_search_telemetry(const mdr_index* h, int nq, int k, const void* workspace_dev, int64_t* out4_host, void* stream) {
     MDR_REQUIRE(h && workspace_dev && out4_host, "NULL argument");

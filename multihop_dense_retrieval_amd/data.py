@@ -30,16 +30,36 @@ def truncate_longest_first_2_11(la, lb, budget):
     return s - r // 2, s - (r + 1) // 2
 
 
+# transformers 2.11 `RobertaTokenizer.prepare_for_tokenization(text, add_special_tokens=False, **kw)` prepends ONE space to a text that
+# does not start with whitespace whenever `add_prefix_space` (default: = add_special_tokens) is on, and `encode_plus` /
+# `batch_encode_plus` call `tokenize(text, add_special_tokens=True)` for EVERY segment -- so under the reference's pin
+# (requirements.txt:1) the question, the title and the passage text each start with a "G-dot" (space-prefixed) BPE token. From 3.0 on
+# add_prefix_space is a constructor argument that defaults to False, which is what the installed tokenizer does. Restated from the
+# 2.11 source as remembered (the package is not installable offline: UNPINNED); one switch for every call site.
+PREFIX_SPACE_2_11 = True
+
+
+def is_roberta_family(tokenizer):
+    return "Roberta" in tokenizer.__class__.__name__
+
+
+def prefix_space_2_11(text):
+    """The text as transformers 2.11's RoBERTa tokenizer sees it inside encode_plus (see PREFIX_SPACE_2_11)."""
+    if PREFIX_SPACE_2_11 and text and not text[0].isspace():
+        return " " + text
+    return text
+
+
 def encode_pairs_2_11(tokenizer, firsts, seconds, max_length, pad_to_max_length):
     """`encode_plus(a, text_pair=b, max_length=n[, pad_to_max_length=True])` of transformers 2.11 for RoBERTa-family
-    tokenizers on top of ANY HF tokenizer version: the tokenizer only supplies the BPE (each text tokenised on its own, no
-    special tokens, no truncation); the pair template `<s> A </s></s> B </s>`, the reference's truncation rule and the
-    right-padding are applied here. Returns (list of id lists, list of mask lists)."""
-    ta = tokenizer(list(firsts), add_special_tokens=False, truncation=False)["input_ids"]
-    tb = tokenizer(list(seconds), add_special_tokens=False, truncation=False)["input_ids"]
+    tokenizers on top of ANY HF tokenizer version: the tokenizer only supplies the BPE (each text tokenised on its own with
+    2.11's prefix space, no special tokens, no truncation); the pair template `<s> A </s></s> B </s>`, the reference's
+    truncation rule and the right-padding are applied here. Returns (list of id lists, list of mask lists)."""
+    if not is_roberta_family(tokenizer):
+        raise TypeError("encode_pairs_2_11 restates the RoBERTa pair template; other tokenizer families use their own call")
+    ta = tokenizer([prefix_space_2_11(t) for t in firsts], add_special_tokens=False, truncation=False)["input_ids"]
+    tb = tokenizer([prefix_space_2_11(t) for t in seconds], add_special_tokens=False, truncation=False)["input_ids"]
     bos, eos, pad = tokenizer.bos_token_id, tokenizer.eos_token_id, tokenizer.pad_token_id
-    if bos is None:  # BERT-style vocabularies name them cls / sep
-        bos, eos = tokenizer.cls_token_id, tokenizer.sep_token_id
     ids_out, mask_out = [], []
     for a, b in zip(ta, tb):
         na, nb = truncate_longest_first_2_11(len(a), len(b), max_length - 4)
@@ -110,10 +130,10 @@ class EmDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, index):
         sample = self.data[index]
-        if "Roberta" in self.tokenizer.__class__.__name__ and sample["text"].strip() == "":
+        if is_roberta_family(self.tokenizer) and sample["text"].strip() == "":
             print(f"empty doc title: {sample['title']}")
             sample["text"] = sample["title"]
-        if "Roberta" in self.tokenizer.__class__.__name__:  # the reference's truncation rule, whatever the HF version's is
+        if is_roberta_family(self.tokenizer):  # the reference's prefix-space and truncation rules, whatever the HF version's are
             ids, mask = encode_pairs_2_11(self.tokenizer, [normalize(sample["title"].strip())], [sample["text"].strip()], self.max_len, False)
             return {"input_ids": torch.tensor(ids, dtype=torch.int64), "attention_mask": torch.tensor(mask, dtype=torch.int64)}
         return self.tokenizer(normalize(sample["title"].strip()), text_pair=sample["text"].strip(), max_length=self.max_len,

@@ -232,13 +232,14 @@ class SyntheticTwoHop:
         return q, D, I
 
     def _step_pipelined(self):
-        """Batches are independent, so hop 2 of batch i and hop 1 of batch i+1 share ONE encoder forward (the packed,
-        un-padded execution takes 350- and 70-token rows in one call) and ONE corpus pass (B*beam + B queries; more than
-        128 queries go 256 per pass). Every question still walks hop-1 encode -> search -> hop-2 assembly -> hop-2 encode
-        -> search -> path ranking with the same arithmetic; what changes is that the small, latency-bound hop-1 work rides
-        along with the previous batch's large hop-2 work instead of paying its own ~140 launches and its own corpus pass.
-        In the steady state one call finishes one batch and starts the next, i.e. per step exactly one hop-1 and one hop-2
-        of every kind of work, as in the sequential step."""
+        """Batches are independent, so hop 2 of batch i and hop 1 of batch i+1 run as TWO CONCURRENT encoder forwards (two lanes
+        = two workspaces and graph caches on two streams, the same weights; one merged 22.6 k-token forward measured slower,
+        DESIGN.md §6) and share ONE fused corpus pass (B*beam + B queries; more than 128 queries go 256 per pass). Every
+        question still walks hop-1 encode -> search -> hop-2 assembly -> hop-2 encode -> search -> path ranking with the same
+        arithmetic; what changes is that the small, latency-bound hop-1 forward runs beside the previous batch's large hop-2
+        forward and that its queries ride in that batch's corpus pass. In the steady state one call finishes one batch and
+        starts the next, i.e. per step exactly one hop-1 and one hop-2 of every kind of work, as in the sequential step.
+        `stage_ms()["hop2_encode"]` of this loop is the wall time of BOTH forwards (main stream, waits for the side stream)."""
         if self._carry is None:
             self._carry = self._hop1_only()
             self._search_ev = self._search_ev[:-1] if self._search_ev else self._search_ev  # the prologue is not a timed call

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the encoder GEMM kernels through the mdr_test_gemm_f16 hook (HIP events, 20 launches each).
-usage: python scripts/gpu_gemm_bench.py [M] [kernels...]"""
+usage: python scripts/gpu_gemm_bench.py [M] [kernels...]
+Ablations / the timeline are VARIANT BUILDS (python -m multihop_dense_retrieval_amd.build -DMDR_GEMM_ABL=n --out=libmdrhip_abl<n>.so),
+selected with MDR_LIB_PATH (scripts/gpu_gemm_ab.sh interleaves several); the product library has no such switch."""
 import os
 import sys
 
@@ -49,7 +51,7 @@ for name, N, K, epi in SHAPES:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         print(f"{name:5s} M={M} N={N} K={K} kernel {kern}{'' if knob is None else ' ' + knob[0] + '=' + knob[1]}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
-        if os.environ.get("MDR_GEMM_ABL") == "5" and kern in (6, 7):  # s_memtime timeline of wave 0, shader cycles per K-tile
+        if hasattr(L, "mdr_test_gemm_stamps") and kern in (6, 7):  # a -DMDR_GEMM_ABL=5 build (MDR_LIB_PATH): s_memtime timeline of wave 0, shader cycles per K-tile
             import ctypes
             buf = (ctypes.c_uint64 * 8)()
             _lib.check(L.mdr_test_gemm_stamps(buf, 1))

@@ -31,7 +31,7 @@ for name, q in (("random", torch.randn((NQ, 768), generator=g, device=dev)), ("p
         same_i = bool((res[v][1] == res[2][1]).all()); dmax = float((res[v][0] - res[2][0]).abs().max())
         print(f"   variant {v} vs exact: ids equal {same_i}  max |dD| {dmax:.3e}")
 
-if os.environ.get("I8_STAMPS"):
+if os.environ.get("I8_STAMPS"):  # needs a -DMDR_I8_ABL=9 build selected with MDR_LIB_PATH
     import ctypes
     from multihop_dense_retrieval_amd import _lib
     buf = (ctypes.c_uint64 * 8)()

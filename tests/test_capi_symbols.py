@@ -30,6 +30,30 @@ def test_library_builds_loads_and_exports_everything():
     assert b"gfx950" in lib.mdr_version()
 
 
+def test_product_library_holds_no_measurement_code():
+    """switches that make a kernel return wrong numbers (ablations) or that record timelines are COMPILE-TIME
+    macros of variant builds. The product library therefore (a) exports none of include/mdr_hip_measure.h, (b) does not contain the
+    names of those switches as strings (nothing reads them from the environment), and (c) the only environment variables the
+    native sources read are the ones below, each of which selects between kernels that return the same results."""
+    import glob
+    from multihop_dense_retrieval_amd import build
+    path = build.build_lib()
+    lib = ctypes.CDLL(path)
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mdr_hip_measure.h")).read(), flags=re.S)
+    hooks = sorted(set(re.findall(r"\b(mdr_[a-z0-9_]+)\s*\(", text)))
+    assert hooks == ["mdr_test_gemm_stamps", "mdr_test_i8_stamps"]
+    for name in hooks:
+        assert not hasattr(lib, name), f"{name} is a measurement hook but the product library exports it"
+    blob = open(path, "rb").read()
+    for knob in (b"MDR_GEMM_ABL", b"MDR_GEMM_EPI", b"MDR_I8_ABL", b"MDR_ATTN_ABL", b"g_gemm_stamp", b"g_i8_stamp"):
+        assert knob not in blob, f"{knob!r} found in the product library"
+    allowed = {"MDR_GEMM_CFG", "MDR_MIPS_WIDE", "MDR_MIPS_I8"}
+    seen = set()
+    for src in glob.glob(os.path.join(ROOT, "multihop_dense_retrieval_amd", "csrc", "*")):
+        seen |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(src).read()))
+    assert seen <= allowed, f"environment variables read by the native sources: {sorted(seen)}; result-neutral ones allowed: {sorted(allowed)}"
+
+
 def test_product_path_fails_loudly_without_a_device():
     import torch
     if torch.cuda.is_available():

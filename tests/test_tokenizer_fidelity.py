@@ -12,6 +12,13 @@ The 2.11 contract is restated as a literal loop (`contract_pair`): `<s> A </s></
 strategy 'longest_first' = pop one token at a time from the longer sequence (from B on a tie), right-pad with the pad id
 to max_length. The installed tokenizer class is checked against that loop first, so the loop is pinned by HF itself and
 not only by our reading of it.
+
+Prefix space. transformers 2.11's RobertaTokenizer.prepare_for_tokenization puts ONE space in front of every
+segment that does not start with whitespace when special tokens are added (add_prefix_space defaults to add_special_tokens
+there; from 3.0 on it is a constructor flag that defaults to False). `p211` restates that rule here, independently of the
+product helper (data.prefix_space_2_11); it is UNPINNED -- remembered from the 2.11 source, which cannot be installed
+offline -- and `test_prefix_space_switch...` shows what the switch changes and that turning it off gives the installed
+tokenizer's own encoding.
 """
 import json
 import os
@@ -53,14 +60,24 @@ def bare(tok, text):
     return tok(text, add_special_tokens=False)["input_ids"]
 
 
+def p211(text):
+    """transformers 2.11 RobertaTokenizer.prepare_for_tokenization(text, add_special_tokens=True)"""
+    return " " + text if text and not text[0].isspace() else text
+
+
+def seg(tok, text):
+    """BPE ids of one segment as 2.11's encode_plus produces them"""
+    return bare(tok, p211(text))
+
+
 def contract_single(tok, text, n):
-    a = bare(tok, text)[: n - 2]
+    a = seg(tok, text)[: n - 2]
     ids = [0] + a + [2]
     return ids + [1] * (n - len(ids)), [1] * len(ids) + [0] * (n - len(ids))
 
 
 def contract_pair(tok, a_text, b_text, n, pad=True):
-    a, b = list(bare(tok, a_text)), list(bare(tok, b_text))
+    a, b = list(seg(tok, a_text)), list(seg(tok, b_text))
     while len(a) + len(b) + 4 > n:  # transformers 2.11 truncate_sequences('longest_first'), one token at a time
         if len(a) > len(b):
             a.pop()
@@ -136,9 +153,56 @@ def test_installed_hf_pair_truncation_against_the_2_11_rule(tok):
     assert differ > 0  # the divergence is real with this transformers version; if it disappears, the note above is stale
 
 
+def test_prefix_space_switch_and_the_installed_tokenizer(tok):
+    """(a) The rule changes the BPE of the FIRST word of a segment only (its space-prefixed form), (b) a segment that already starts
+    with whitespace is left alone, (c) with the switch off the product path is exactly the installed tokenizer's own call."""
+    from multihop_dense_retrieval_amd import data
+    from multihop_dense_retrieval_amd.eval_mhop_retrieval import _tokenize
+    a, b = seg(tok, "Paris lies on the Seine"), bare(tok, "Paris lies on the Seine")
+    assert a[0] != b[0] and a[-4:] == b[-4:] and tok.decode(a) == " " + tok.decode(b)
+    assert seg(tok, " The quick") == bare(tok, " The quick")
+    assert seg(tok, "") == bare(tok, "")
+    assert data.prefix_space_2_11("Paris") == p211("Paris") == " Paris" and data.prefix_space_2_11("\tx") == "\tx"
+    on = _tokenize(tok, QUESTIONS, None, 70)["input_ids"]
+    data.PREFIX_SPACE_2_11 = False
+    try:
+        off = _tokenize(tok, QUESTIONS, None, 70)["input_ids"]
+        pairs_off = _tokenize(tok, None, [("Which band", "Paris is"), ("a", "q")], 64)["input_ids"]
+    finally:
+        data.PREFIX_SPACE_2_11 = True
+    hf = tok(QUESTIONS, max_length=70, padding="max_length", truncation=True, return_tensors="pt")["input_ids"]
+    assert torch.equal(off, hf) and not torch.equal(on, hf)
+    hfp = tok(["Which band", "a"], ["Paris is", "q"], max_length=64, padding="max_length", truncation="longest_first", return_tensors="pt")["input_ids"]
+    assert torch.equal(pairs_off, hfp)
+
+
+def test_other_tokenizer_families_use_their_own_pair_call():
+    """the RoBERTa template must not be applied to a BERT-style tokenizer (`[CLS] a [SEP] b [SEP]` + token_type_ids)."""
+    from multihop_dense_retrieval_amd import data
+    from multihop_dense_retrieval_amd.eval_mhop_retrieval import _tokenize
+
+    class FakeBertTokenizer:
+        def __init__(self):
+            self.calls = []
+
+        def __call__(self, a, b=None, **kw):
+            self.calls.append((a, b, kw))
+            return {"input_ids": torch.zeros((len(a), kw["max_length"]), dtype=torch.int64)}
+
+    t = FakeBertTokenizer()
+    assert not data.is_roberta_family(t)
+    _tokenize(t, None, [("q1", "d1"), ("q2", "d2")], 32)
+    a, b, kw = t.calls[-1]
+    assert a == ["q1", "q2"] and b == ["d1", "d2"] and kw["truncation"] == "longest_first" and kw["padding"] == "max_length"
+    _tokenize(t, ["q1"], None, 16)
+    assert t.calls[-1][0] == ["q1"]  # no prefix space for other families
+    with pytest.raises(TypeError):
+        data.encode_pairs_2_11(t, ["a"], ["b"], 16, True)
+
+
 def test_second_sequence_is_tokenised_like_a_standalone_text(tok):
-    """Byte-level BPE adds no prefix space in pair position (add_prefix_space=False): the arena may therefore tokenise
-    every passage ONCE, standalone, and splice it behind any question."""
+    """Byte-level BPE adds no prefix space of its own in pair position (add_prefix_space=False in the installed version): the arena
+    may therefore tokenise every passage ONCE, standalone (with 2.11's explicit space in front), and splice it behind any question."""
     for d in DOCS.values():
         text = d["text"] if d["text"].strip() else d["title"]
         enc = tok("Which band", text)["input_ids"]
@@ -172,7 +236,7 @@ def test_arena_holds_the_standalone_tokens(tok):
     for i in range(len(DOCS)):
         d = DOCS[str(i)]
         text = d["text"] if d["text"].strip() else d["title"]
-        assert ar.tokens[off[i]:off[i + 1]].tolist() == bare(tok, text)[:350]
+        assert ar.tokens[off[i]:off[i + 1]].tolist() == seg(tok, text)[:350]
     assert ar.empty.tolist() == [0, 0, 1, 0, 0, 0, 0]
 
 
