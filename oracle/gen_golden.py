@@ -63,11 +63,48 @@ def _ref_models(geom, sd_np, tmp):
     return q, c, cfg, args, ckpt
 
 
+def o1_mode(literal):
+    """apex-O1 numerics (the regime the reference publishes its numbers under, eval_mhop_retrieval.py:86-90) imposed on the
+    IMPORTED reference model on the CPU, as a torch-function mode: every Linear / matmul ("whitelist" ops, run by apex in fp16 on
+    tensor cores with fp32 accumulation) sees its inputs and weights ROUNDED TO FP16; LayerNorm, softmax, GELU ("blacklist" ops)
+    and the embedding sums stay fp32.
+      literal = False ("o1ops"): only the operand rounding -- products and sums in fp32, outputs not rounded. This is the dataflow of
+                the HIP encoder in residual_fp32 mode, so HIP-vs-this isolates kernel error from the regime's own rounding.
+      literal = True  ("o1lit"): additionally what apex O1 literally does with the OUTPUTS of those ops: a Linear returns an fp16
+                tensor (matmul result rounded to fp16, then `+= bias` in fp16: torch's F.linear for 3-D inputs), torch.matmul
+                returns fp16 (attention scores and context). More roundings than the HIP path performs."""
+    import torch
+    import torch.nn.functional as F
+    from torch.overrides import TorchFunctionMode
+
+    def r(t):
+        return t.half().float()
+
+    class Mode(TorchFunctionMode):
+        def __torch_function__(self, func, types, args=(), kwargs=None):
+            kwargs = kwargs or {}
+            if func is F.linear:
+                x, w = args[0], args[1]
+                b = args[2] if len(args) > 2 else kwargs.get("bias")
+                y = func(r(x), r(w))
+                if literal:
+                    y = r(y)
+                    return r(y + r(b)) if b is not None else y
+                return y + b if b is not None else y
+            if func in (torch.matmul, torch.Tensor.matmul, torch.Tensor.__matmul__, torch.bmm):
+                y = func(r(args[0]), r(args[1]))
+                return r(y) if literal else y
+            return func(*args, **kwargs)
+
+    return Mode()
+
+
 def gen_encoder(tmp):
     import torch
     cases = {
         "tiny": (seeded.TINY, 11, [("q", 4, 70, 1), ("qsp", 3, 350, 1), ("ctx", 5, 97, 0), ("one", 1, 8, 1)]),
         "base": (seeded.ROBERTA_BASE, 7, [("q", 3, 70, 1), ("qsp", 2, 350, 1), ("ctx", 2, 300, 0)]),
+        "wide2": (seeded.WIDE2, 13, [("q", 6, 70, 1), ("qsp", 3, 350, 1)]),
     }
     for tag, (geom, seed, batches) in cases.items():
         sd = seeded.make_state_dict(seed, geom)
@@ -83,6 +120,15 @@ def gen_encoder(tmp):
             print(f"encoder {tag}.{name}: ref-vs-restatement(f64) max abs diff {np.abs(mine - eq).max():.3e}, "
                   f"|out| mean {np.abs(eq).mean():.3f}")
             out[f"{name}.ids"], out[f"{name}.mask"], out[f"{name}.embed"] = ids, mask, eq.astype(np.float32)
+            # the same reference model under apex-O1 numerics (operand rounding only / literal): VERDICT r2 item 2
+            for key, literal in (("embed_o1ops", False), ("embed_o1lit", True)):
+                with torch.no_grad(), o1_mode(literal):
+                    eo = q.encode_q(torch.from_numpy(ids), torch.from_numpy(mask), None).numpy()
+                from oracle import roberta_torch
+                mine_o = roberta_torch.encode(sd, geom, ids, mask, torch.float32, "cpu", o1="literal" if literal else "operands").numpy()
+                print(f"    {key}: |o1 - fp32| max {np.abs(eo - eq).max():.3e} mean {np.abs(eo - eq).mean():.3e}; "
+                      f"restatement(o1) vs reference(o1) max {np.abs(mine_o - eo).max():.3e}")
+                out[f"{name}.{key}"] = eo.astype(np.float32)
         np.savez_compressed(os.path.join(GOLD, f"encoder_{tag}.npz"), **out)
 
 

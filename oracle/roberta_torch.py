@@ -7,7 +7,12 @@ box in seconds (the numpy version needs minutes there). Plain torch fp64 -- no c
 product path. Pinned by tests/test_oracle_encoder.py::test_torch_restatement_equals_numpy_restatement (<= 1e-9 in fp64),
 the numpy restatement in turn by the reference's own outputs (tests/golden/encoder_*.npz).
 
-Only tests/ may import this module.
+`o1`: apex-O1 numerics restated (the regime of eval_mhop_retrieval.py:86-90; pinned by the fixtures `*.embed_o1ops` / `*.embed_o1lit`
+that oracle/gen_golden.py produces from the IMPORTED reference model under a torch-function mode):
+    "operands"  Linear / matmul inputs and weights rounded to fp16, products and sums in `dtype`, outputs not rounded
+    "literal"   additionally the outputs of Linear (matmul result, then the bias add) and of the attention matmuls rounded to fp16
+
+Only tests/ (and oracle/gen_golden.py) may import this module.
 """
 import math
 
@@ -20,9 +25,20 @@ def layer_norm(x, g, b, eps):
     return (x - mu) / torch.sqrt(var + eps) * g + b
 
 
-def encode(sd, geom, input_ids, attention_mask, dtype=torch.float64, device="cpu", chunk=64):
+def encode(sd, geom, input_ids, attention_mask, dtype=torch.float64, device="cpu", chunk=64, o1=None):
     """sd: name -> numpy / torch tensors (fp32 checkpoint values). -> [B, hidden] tensor of `dtype` on `device`."""
+    assert o1 in (None, "operands", "literal")
     W = {k: torch.as_tensor(v).to(device=device, dtype=dtype) for k, v in sd.items() if "pooler" not in k}
+
+    def r(t):  # fp16 rounding of a GEMM operand (or, literal mode, of a GEMM output)
+        return t.to(torch.float16).to(dtype) if o1 else t
+
+    def ro(t):
+        return t.to(torch.float16).to(dtype) if o1 == "literal" else t
+
+    def linear(t, w, b):
+        y = ro(r(t) @ r(w).T)
+        return ro(y + r(b)) if o1 == "literal" else y + b
     H, nh, eps, pad = geom["hidden"], geom["heads"], geom["ln_eps"], geom["pad_id"]
     hd = H // nh
     ids_all = torch.as_tensor(input_ids).to(device)
@@ -41,18 +57,18 @@ def encode(sd, geom, input_ids, attention_mask, dtype=torch.float64, device="cpu
             p = f"encoder.encoder.layer.{i}."
 
             def lin(t, n):
-                return t @ W[p + n + ".weight"].T + W[p + n + ".bias"]
+                return linear(t, W[p + n + ".weight"], W[p + n + ".bias"])
             q = lin(x, "attention.self.query").reshape(B, L, nh, hd).permute(0, 2, 1, 3)
             k = lin(x, "attention.self.key").reshape(B, L, nh, hd).permute(0, 2, 1, 3)
             v = lin(x, "attention.self.value").reshape(B, L, nh, hd).permute(0, 2, 1, 3)
-            s = q @ k.transpose(-1, -2) / math.sqrt(hd) + add_mask
+            s = ro(r(q) @ r(k).transpose(-1, -2)) / math.sqrt(hd) + add_mask
             pr = torch.softmax(s, -1)
-            ctx = (pr @ v).permute(0, 2, 1, 3).reshape(B, L, H)
+            ctx = ro(r(pr) @ r(v)).permute(0, 2, 1, 3).reshape(B, L, H)
             x = layer_norm(lin(ctx, "attention.output.dense") + x, W[p + "attention.output.LayerNorm.weight"],
                            W[p + "attention.output.LayerNorm.bias"], eps)
             h = lin(x, "intermediate.dense")
             h = 0.5 * h * (1.0 + torch.erf(h / math.sqrt(2.0)))
             x = layer_norm(lin(h, "output.dense") + x, W[p + "output.LayerNorm.weight"], W[p + "output.LayerNorm.bias"], eps)
-        y = x[:, 0, :] @ W["project.0.weight"].T + W["project.0.bias"]
+        y = linear(x[:, 0, :], W["project.0.weight"], W["project.0.bias"])
         outs.append(layer_norm(y, W["project.1.weight"], W["project.1.bias"], eps))
     return torch.cat(outs)

@@ -19,6 +19,21 @@ torch = pytest.importorskip("torch")
 TOL = {"tiny": (6e-3, 1.2e-3), "base": (1.2e-2, 2e-3)}
 
 
+# Operand-rounded parity. The fixtures also hold the IMPORTED reference model's outputs under apex-O1 operand
+# numerics (`*.embed_o1ops`: Linear / matmul operands rounded to fp16, everything else fp32 -- exactly the HIP encoder's dataflow in
+# residual_fp32 mode) and under literal apex O1 (`*.embed_o1lit`: outputs of those ops rounded to fp16 as well). fp16 rounding is a
+# discontinuous map, so two CORRECT implementations of the same O1 arithmetic that differ only in fp32 summation order drift apart
+# at every rounding: on the CPU, oracle/roberta_torch.py(o1) vs the hooked reference is 0.3-0.6 of the regime's own error against
+# fp32 at depth 2 and 0.8 at depth 12 (tests/test_oracle_encoder.py::test_o1_restatement...). The bars are therefore relative to
+# e_regime = mean |o1ops - fp32| of the same fixture case:
+#   (a) mean |HIP - fp32|  <= A * e_regime : the HIP encoder is as close to the fp32 reference as the reference's own O1 regime is
+#   (b) mean |HIP - o1ops| <= B * e_regime : and closer to the O1 outputs than O1 is to fp32 -- sharp on the SHALLOW full-width stack
+#       (wide2: one full layer + the CLS layer on roberta-base tile shapes), where a kernel defect of ~3e-4 mean shows; at depth 12
+#       two correct implementations are already 0.8 apart, so there the bar only bounds the decorrelation.
+# measured (round 3, MI355X): see the printed lines in profiles/r03_*pytest_gpu.txt
+O1_BARS = {"tiny": (1.25, 0.90), "wide2": (1.25, 0.90), "base": (1.20, 1.05)}
+
+
 def build(geom, seed, cls=None, residual_fp32=None):
     from multihop_dense_retrieval_amd import retriever
     cfg = retriever.RobertaConfig(vocab_size=geom["vocab"], hidden_size=geom["hidden"], num_hidden_layers=geom["layers"],
@@ -56,6 +71,27 @@ def test_fp32_residual_stream_mode_matches_reference(golden, tag, name):
     err = np.abs(out.cpu().numpy() - g[f"{name}.embed"])
     print(f"encoder {tag}.{name} (fp32 residual): max abs err {err.max():.3e} mean {err.mean():.3e}")
     assert err.max() <= TOL[tag][0] and err.mean() <= TOL[tag][1]
+
+
+@pytest.mark.parametrize("residual_fp32", [True, False])
+@pytest.mark.parametrize("tag,name", [("tiny", "q"), ("tiny", "qsp"), ("wide2", "q"), ("wide2", "qsp"), ("base", "q"), ("base", "qsp")])
+def test_distance_to_the_operand_rounded_reference(golden, tag, name, residual_fp32):
+    g = golden(f"encoder_{tag}.npz")
+    geom = {"tiny": seeded.TINY, "wide2": seeded.WIDE2, "base": seeded.ROBERTA_BASE}[tag]
+    m, _ = build(geom, int(g["seed"]), residual_fp32=residual_fp32)
+    out = m.encode_q(torch.from_numpy(g[f"{name}.ids"]).cuda(), torch.from_numpy(g[f"{name}.mask"]).cuda(), None).cpu().numpy()
+    f32, ops, lit = g[f"{name}.embed"], g[f"{name}.embed_o1ops"], g[f"{name}.embed_o1lit"]
+    e_regime = np.abs(ops - f32).mean()
+    d32, dops, dlit = np.abs(out - f32), np.abs(out - ops), np.abs(out - lit)
+    print(f"encoder {tag}.{name} residual_fp32={int(residual_fp32)}: e_regime {e_regime:.3e} | HIP-fp32 mean {d32.mean():.3e} max {d32.max():.3e} "
+          f"({d32.mean() / e_regime:.2f} x) | HIP-o1ops mean {dops.mean():.3e} max {dops.max():.3e} ({dops.mean() / e_regime:.2f} x) | "
+          f"HIP-o1lit mean {dlit.mean():.3e} max {dlit.max():.3e}")
+    A, B = O1_BARS[tag]
+    if not residual_fp32:  # one more fp16 rounding per LayerNorm than apex O1 performs (the default, faster mode): reported, looser
+        A, B = A + 0.15, B + 0.15
+    assert d32.mean() <= A * e_regime, (d32.mean(), e_regime)
+    assert dops.mean() <= B * e_regime, (dops.mean(), e_regime)
+    assert dops.max() <= 4.0 * np.abs(ops - f32).max()
 
 
 def test_ctx_encoder_forward_matches_encode_q(models, golden):

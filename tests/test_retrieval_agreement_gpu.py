@@ -55,10 +55,18 @@ def test_top1_and_top4_ids_agree_with_fp64_reference_embeddings(residual_fp32):
         ids, mask = token_batch(g, B, L, lo, hi, geom["vocab"])
         e_hip = enc.encode_q(ids, mask, None)
         e_ref = roberta_torch.encode(sd, geom, ids, mask, torch.float64, "cuda", chunk=50)
+        # the reference's OWN regime: the same forward under apex-O1 operand numerics (oracle/roberta_torch.py, pinned by the
+        # `embed_o1ops` fixtures of the imported reference model). How often apex O1 itself moves the top-1 id away from the exact
+        # embedding's is the yardstick for the HIP encoder: it must not move it more often than that.
+        e_o1 = roberta_torch.encode(sd, geom, ids, mask, torch.float64, "cuda", chunk=50, o1="operands")
         err = (e_hip.double() - e_ref).abs()
         D1, I1 = idx.search_device(e_hip.contiguous(), 4)
         D2, I2 = idx.search_device(e_ref.float().contiguous(), 4)
+        _, I3 = idx.search_device(e_o1.float().contiguous(), 4)
         top1 = float((I1[:, 0] == I2[:, 0]).float().mean())
+        regime_top1 = float((I3[:, 0] == I2[:, 0]).float().mean())
+        hip_vs_o1_top1 = float((I1[:, 0] == I3[:, 0]).float().mean())
+        regime_err = float((e_o1 - e_ref).abs().mean())
         set4 = float(torch.tensor([len(set(a.tolist()) & set(b.tolist())) / 4.0 for a, b in zip(I1.cpu(), I2.cpu())]).mean())
         # a top-1 disagreement must be a near-tie under the REFERENCE embedding: the two rows' scores differ by less than
         # the score shift the embedding error can cause (|e_hip - e_ref| . |row| <~ 27.7 * |delta|)
@@ -68,7 +76,8 @@ def test_top1_and_top4_ids_agree_with_fp64_reference_embeddings(residual_fp32):
             sc = (D2[b, 0] - (D2[b][I2[b] == I1[b, 0]][0] if bool((I2[b] == I1[b, 0]).any()) else D2[b, 3])).item()
             shift = float((e_hip[b].double() - e_ref[b]).norm()) * 27.8 * 2
             gap_ok &= sc <= shift
-        report[name] = dict(n=B, emb_max_abs_err=float(err.max()), emb_mean_abs_err=float(err.mean()), top1_agreement=top1,
+        report[name] = dict(n=B, emb_max_abs_err=float(err.max()), emb_mean_abs_err=float(err.mean()), o1_regime_emb_mean_abs_err=regime_err,
+                            o1_regime_top1_agreement_with_exact=regime_top1, hip_top1_agreement_with_o1_regime=hip_vs_o1_top1, top1_agreement=top1,
                             top4_set_overlap=set4, top1_score_gap_mean=float((D2[:, 0] - D2[:, 1]).mean()), disagreements_are_near_ties=bool(gap_ok))
     print(f"retrieval agreement, residual_fp32={residual_fp32}: HIP (fp16 MFMA) vs fp64 reference embeddings:", report)
     for name, r in report.items():
@@ -76,3 +85,8 @@ def test_top1_and_top4_ids_agree_with_fp64_reference_embeddings(residual_fp32):
         # this corpus is adversarially dense (random-token passages through a random-init encoder: mean top-1 margin ~1.0 on
         # scores of ~100, 1-2 % of the questions have a runner-up within the fp16-operand noise)
         assert r["top1_agreement"] >= 0.97 and r["top4_set_overlap"] >= 0.97 and r["emb_max_abs_err"] <= 1.2e-2, (name, r)
+        # ... and relative to the reference's own regime: the HIP embeddings are no further from the exact ones than apex-O1 operand
+        # rounding puts them (15 % statistical slack on the mean error), and change the top-1 passage no more often (1 % of the
+        # questions slack: 2-10 questions of these samples)
+        assert r["emb_mean_abs_err"] <= 1.15 * r["o1_regime_emb_mean_abs_err"], (name, r)
+        assert r["top1_agreement"] >= r["o1_regime_top1_agreement_with_exact"] - 0.01, (name, r)
