@@ -27,8 +27,9 @@ Prints ONE JSON line on rank 0 with
 
 roofline.traffic is HBM bytes per search call from a separate `rocprofv3 --pmc FETCH_SIZE` pass (scripts/gpu_pmc_screen.sh;
 KB x 1024 x 2, the gfx950 correction of MI355X_MICROARCH.md), which cannot run inside this process: the measured ratio
-traffic / algorithmic bytes of each kernel (table below, source files under profiles/) is applied to this run's
-algorithmic bytes, or pass --pmc-traffic with a fresh measurement.
+traffic / algorithmic bytes of each kernel family (profiles/pmc_traffic.json, written by that script with the hash of
+csrc/mdr_mips.hip at measurement time) is applied to this run's algorithmic bytes -- `traffic_fresh` is false and
+`traffic_source` says STALE when the kernel source has changed since -- or pass --pmc-traffic with a fresh measurement.
 """
 import argparse
 import json
@@ -46,18 +47,24 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense fp16/bf16 MFMA peak
 CHUNK_ROWS = 250_000
 
-# measured HBM fetch bytes per search call / algorithmic bytes (N_pad * d * 4), from rocprofv3 --pmc FETCH_SIZE passes
-PMC_TRAFFIC_RATIO = {
-    # 16 queries per wave: main 3.75164e6 KB + refine 29030 KB + sample 25376 KB, x2 -> 7.794e9 B per search at 5M x 768 (15.36e9 B algorithmic)
-    "mips_screen_kernel": (0.5074, "profiles/r02_mips5m_pmc_sequential_FETCH_SIZE.csv"),
-    # 32 queries per wave: main 3.75258e6 KB + refine 52561 KB + sample 26145 KB, x2 -> 7.847e9 B per search (200 queries)
-    "mips_screen32_kernel": (0.5109, "profiles/r02_mips5m_pmc_pipelined_FETCH_SIZE.csv"),
-    "mips_stream_kernel": (1.001, "profiles/r01_mips1m_pmc_fetch_size.csv"),
-    # int8 screening tier (776 B per row), 16 queries per wave: main 1.89632e6 KB + sample 25255 + refine 1955 + 2 x star 1364, x2 -> 3.945e9 B per search
-    "mips_screen8_kernel": (0.2568, "profiles/r02_mips5m_i8_pmc_sequential_FETCH_SIZE.csv"),
-    # 32 queries per wave: main 1.89644e6 KB + sample 25700 + refine 2929 + 2 x star 2447, x2 -> 3.953e9 B per search (200 queries)
-    "mips_screen8w_kernel": (0.2573, "profiles/r02_mips5m_i8_pmc_pipelined_FETCH_SIZE.csv"),
-}
+# measured HBM fetch bytes per search call / algorithmic bytes (N_pad * d * 4) per kernel family: profiles/pmc_traffic.json, written by
+# scripts/gpu_pmc_screen.sh (rocprofv3 --pmc FETCH_SIZE passes) together with the hash of csrc/mdr_mips.hip at measurement time.
+MIPS_SRC = os.path.join(ROOT, "multihop_dense_retrieval_amd", "csrc", "mdr_mips.hip")
+
+
+def src_sha16(path=MIPS_SRC):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def load_pmc_table():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+    except (OSError, KeyError, ValueError):
+        return {}
 
 
 def parse():
@@ -211,11 +218,16 @@ def mips_roofline(pipe, local, args, d):
     tot_ms = sum(ms for ms, _ in calls)
     alg_bytes = float(sum(shard_bytes * p for p in passes))
     kname = local.last_kernel()
-    ratio, src = (1.0, "designed (no counter profile for this kernel / shape)")
+    ratio, src, fresh = 1.0, "designed (no counter profile for this kernel / shape)", None
     if args.pmc_traffic is None:
-        for name, (r_, src_) in PMC_TRAFFIC_RATIO.items():
+        now = src_sha16()
+        for name, ent in load_pmc_table().items():
             if name in kname and d == 768 and args.storage != "bf16":
-                ratio, src = r_, f"{src_} (measured FETCH_SIZE x 2 / algorithmic bytes = {r_})"
+                ratio = float(ent["ratio"])
+                fresh = ent.get("csrc_sha16") is not None and ent.get("csrc_sha16") == now
+                src = (f"{ent['source']} (measured FETCH_SIZE x 2 / algorithmic bytes = {ratio}; "
+                       + ("kernel source unchanged since that measurement" if fresh else
+                          f"STALE: csrc/mdr_mips.hip was {ent.get('csrc_sha16')} when measured, is {now} now -- re-run scripts/gpu_pmc_screen.sh") + ")")
         hbm_bytes = alg_bytes * ratio
     else:
         hbm_bytes, src = float(args.pmc_traffic) * len(calls), "--pmc-traffic"
@@ -224,7 +236,7 @@ def mips_roofline(pipe, local, args, d):
     alg_rate = alg_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
     return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": round(hbm_bytes / n_calls), "traffic_source": src,
+            "traffic": round(hbm_bytes / n_calls), "traffic_source": src, "traffic_fresh": fresh,
             "algorithmic_bytes_per_launch": round(alg_bytes / n_calls),
             "algorithmic_GBps": round(alg_rate, 1),
             "algorithmic_over_physical": round(alg_bytes / hbm_bytes, 3) if hbm_bytes > 0 else None,
@@ -498,7 +510,7 @@ def main():
                                     "global_batch": B, "note": "one batch of --batch questions for all ranks: encoder slices split over ranks + all-gather"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, device)
+        result["cpu_baseline"] = cpu_baseline(args, device, gpu_index=local)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -506,13 +518,16 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, device):
-    """FAISS-equivalent CPU path (kind 'port': faiss is not installed here) on the GPU box's host cores, bounded to
-    ~args.cpu_seconds: the two searches of one 100-question step over a row SAMPLE of the same synthetic corpus, linearly
-    extrapolated to the full row count (flat search is linear in rows). Threads = the cores this container may use
-    (affinity and cgroup quota: the boxes give 16 of the host's 256 hardware threads; 128 OpenMP threads on that quota ran
-    9x slower). Two restatements of the same algorithm are timed on the sample and the faster one is reported:
-    oracle/flat_ip_blas.py (OpenBLAS sgemm behind numpy + top-k, what FAISS itself does) and oracle/flat_ip_oracle.c."""
+def cpu_baseline(args, device, gpu_index=None):
+    """FAISS-equivalent CPU path (kind 'port': faiss is not installed here) on the GPU box's host cores, over ALL rows of the same
+    synthetic corpus, no extrapolation: the corpus is re-generated chunk by chunk (250 k rows; the device RNG
+    that built the index), each chunk is searched on the host by the two searches of one 100-question step (hop 1 + hop 2: the same
+    shape, 100 queries, k = beam), the running top-k is merged exactly as FAISS merges its row blocks, and only the HOST search time
+    is summed (generation and the D2H copy of a chunk are not the baseline's work: FAISS holds the matrix in RAM). Threads = the
+    cores this container may use (affinity and cgroup quota: the boxes give 16 of the host's 256 hardware threads; 128 OpenMP
+    threads on that quota ran 9x slower). Two restatements of the same algorithm are timed on the first chunk and the faster one
+    runs the rest: oracle/flat_ip_blas.py (OpenBLAS sgemm behind numpy + top-k, what FAISS itself does) and oracle/flat_ip_oracle.c.
+    --cpu-seconds bounds the repetitions per chunk, never the rows."""
     import ctypes
     import subprocess
 
@@ -527,53 +542,71 @@ def cpu_baseline(args, device):
     f.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
                   ctypes.c_void_p, ctypes.c_int]
     d, B, k = args.dim, args.batch, args.beam
-    q = corpus_chunk(1, 0, B, d, device).cpu().numpy()
-    D = np.empty((B, k), np.float32)
-    I = np.empty((B, k), np.int64)
+    q_dev = corpus_chunk(1, 0, B, d, device)
+    q = q_dev.cpu().numpy()
 
     def run_c(xb):
+        D = np.empty((B, k), np.float32)
+        I = np.empty((B, k), np.int64)
         t = time.perf_counter()
         rc = f(q.ctypes.data, B, xb.ctypes.data, xb.shape[0], d, k, D.ctypes.data, I.ctypes.data, cores)
         assert rc == 0
-        return time.perf_counter() - t, I.copy()
+        return time.perf_counter() - t, D, I
 
     def run_blas(xb):
         t = time.perf_counter()
-        _, Ib = flat_ip_blas.search(q, xb, k)
-        return time.perf_counter() - t, Ib
+        Db, Ib = flat_ip_blas.search(q, xb, k)
+        return time.perf_counter() - t, Db, Ib
 
     try:
         from threadpoolctl import threadpool_limits
         limiter = threadpool_limits(limits=cores)
     except Exception:
         limiter = None
-    probe = corpus_chunk(0, 0, 100_000, d, device).cpu().numpy()
-    run_c(probe), run_blas(probe)  # warm both (thread pools, page faults)
-    (tc, Ic), (tb, Ib) = run_c(probe), run_blas(probe)
-    agree = float((Ic == Ib).mean())
-    rate = 100_000 / min(tb, tc)  # rows/s for one search call
-    sample_rows = int(min(args.rows, max(100_000, rate * args.cpu_seconds / 2)))
-    sample_rows = min(sample_rows, 4_000_000)  # host RAM bound: 12 GB
-    nchunk = -(-sample_rows // CHUNK_ROWS)
-    xb = np.concatenate([corpus_chunk(0, c, CHUNK_ROWS, d, device).cpu().numpy() for c in range(nchunk)])[:sample_rows]
-    # both restatements on the full sample (the 100k-row probe is too short to rank them reliably on a shared host)
-    t_full = {"blas": min(run_blas(xb)[0], run_blas(xb)[0]), "c_openmp": min(run_c(xb)[0], run_c(xb)[0])}
-    if t_full["blas"] <= t_full["c_openmp"]:
+    nchunk = -(-args.rows // CHUNK_ROWS)
+    first = corpus_chunk(0, 0, CHUNK_ROWS, d, device)[:min(CHUNK_ROWS, args.rows)].cpu().numpy()
+    run_c(first), run_blas(first)  # warm both (thread pools, page faults)
+    t_probe = {"blas": min(run_blas(first)[0], run_blas(first)[0]), "c_openmp": min(run_c(first)[0], run_c(first)[0])}
+    agree = float((run_c(first)[2] == run_blas(first)[2]).mean())
+    if t_probe["blas"] <= t_probe["c_openmp"]:
         run, impl = run_blas, "oracle/flat_ip_blas.py (numpy/OpenBLAS sgemm + top-k, the FAISS algorithm)"
     else:
         run, impl = run_c, "oracle/flat_ip_oracle.c (restatement of faiss IndexFlatIP::search, OpenMP)"
-    t1 = min(t_full.values())
-    reps = int(max(1, min(10, args.cpu_seconds / max(2 * t1, 1e-3))))  # repeat the (hop 1 + hop 2) pair for a steadier number
-    t = sum(run(xb)[0] + run(xb)[0] for _ in range(reps)) / reps
-    if limiter is not None:
-        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
-    step_s = t * (args.rows / sample_rows)
-    return {"value": round(B / step_s, 3), "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"2 flat-IP searches (hop 1 + hop 2) of {B} queries, k={k}, over the first {sample_rows} rows of the same "
-                      f"synthetic corpus in {t:.2f} s (mean of {reps} repetitions) on {cores} threads (the container's CPU quota; host has {os.cpu_count()} hardware "
-                      f"threads), extrapolated linearly to {args.rows} rows; MIPS only (the reference's encoder runs on the GPU in the "
+    # repetitions of the (hop 1 + hop 2) pair per chunk so that the whole baseline is about --cpu-seconds of host work
+    reps = int(max(1, min(5, args.cpu_seconds / max(2 * min(t_probe.values()) * nchunk, 1e-3))))
+    run_D = np.full((B, k), -np.inf, np.float32)
+    run_I = np.full((B, k), -1, np.int64)
+    t_pair_sum, t_all = 0.0, time.perf_counter()
+    for c in range(nchunk):
+        base = c * CHUNK_ROWS
+        n_here = min(CHUNK_ROWS, args.rows - base)
+        xb = (first if c == 0 else corpus_chunk(0, c, CHUNK_ROWS, d, device)[:n_here].cpu().numpy())
+        best = None
+        for _ in range(reps):  # the step's two searches; the fastest repetition of the pair counts (shared host)
+            t1, Dc, Ic = run(xb)
+            t2, _, _ = run(xb)
+            best = t1 + t2 if best is None else min(best, t1 + t2)
+        t0 = time.perf_counter()  # merge this block's top-k into the running one (part of a flat search over all rows)
+        cat_D, cat_I = np.concatenate([run_D, Dc], 1), np.concatenate([run_I, Ic + base], 1)
+        o = np.argsort(-cat_D, 1, kind="stable")[:, :k]
+        run_D, run_I = np.take_along_axis(cat_D, o, 1), np.take_along_axis(cat_I, o, 1)
+        t_pair_sum += best + 2 * (time.perf_counter() - t0)
+        del xb
+    wall = time.perf_counter() - t_all
+    if limiter is not None and hasattr(limiter, "restore_original_limits"):
+        limiter.restore_original_limits()
+    check = None
+    if gpu_index is not None:  # the same queries through the HIP index: the baseline searched the same matrix and found the same rows
+        _, Ig = gpu_index.search_device(q_dev.contiguous(), k)
+        check = round(float((Ig.cpu().numpy() == run_I).mean()), 6)
+    return {"value": round(B / t_pair_sum, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"ALL {args.rows} rows of the same synthetic corpus, streamed in {nchunk} chunks of {CHUNK_ROWS} (no extrapolation): per chunk the 2 "
+                      f"flat-IP searches of one step (hop 1 + hop 2, {B} queries, k={k}), fastest of {reps} repetition(s), + the running top-k merge; "
+                      f"{t_pair_sum:.2f} s of host search time for one step ({wall:.1f} s wall incl. re-generating and copying the chunks) on {cores} threads "
+                      f"(the container's CPU quota; host has {os.cpu_count()} hardware threads); MIPS only (the reference's encoder runs on the GPU in the "
                       f"reference too)",
-            "impl": impl, "one_search_over_sample_s": {k_: round(v, 4) for k_, v in t_full.items()}, "probe_id_agreement": agree}
+            "impl": impl, "one_search_over_first_chunk_s": {k_: round(v, 4) for k_, v in t_probe.items()}, "probe_id_agreement": agree,
+            "rows_searched": int(args.rows), "extrapolated": False, "top1_id_agreement_with_hip_index": check}
 
 
 if __name__ == "__main__":

@@ -190,15 +190,19 @@ class SyntheticTwoHop:
             from .index import all_gather_dim0
             return all_gather_dim0(self.encoder.encode_q(ids, mask, None, lane=lane), self.world)
         if self.world > 1:
-            # data-parallel encoder: each rank encodes a contiguous slice, embeddings are all-gathered
+            # data-parallel encoder (strong scaling): rank r encodes rows r, r + W, r + 2W, ... and the embeddings are all-gathered.
+            # The split is INTERLEAVED, not contiguous, so that the ranks' TOKEN counts (the encoder's cost; hop-2 rows are 64..350
+            # tokens long) balance without a host sync on the lengths -- an exact split by cumulative token count would need the
+            # lengths on the host between the hops. Static row counts per rank also keep the hipGraph shapes fixed.
             n = ids.shape[0]
             per = -(-n // self.world)
-            lo, hi = min(n, self.rank * per), min(n, (self.rank + 1) * per)
+            mine = torch.arange(self.rank, n, self.world, device=ids.device)
             part = torch.zeros((per, self.d), device=self.device)
-            if hi > lo:
-                part[: hi - lo] = self.encoder.encode_q(ids[lo:hi], mask[lo:hi], None, lane=lane)
+            if mine.numel() > 0:
+                part[: mine.numel()] = self.encoder.encode_q(ids[mine], mask[mine], None, lane=lane)
             from .index import all_gather_dim0
-            return all_gather_dim0(part, self.world)[:n].contiguous()
+            g = all_gather_dim0(part, self.world)  # [W * per, d]: entry (r, j) is global row j * W + r
+            return g.view(self.world, per, self.d).transpose(0, 1).reshape(self.world * per, self.d)[:n].contiguous()
         return self.encoder.encode_q(ids, mask, None, lane=lane)
 
     # -- one step ----------------------------------------------------------------------------------------
