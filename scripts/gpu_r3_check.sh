@@ -4,7 +4,7 @@ set -u
 TAG=${1:-r03a}; REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 python -c "import torch; print('torch', torch.__version__, 'gpu', torch.cuda.get_device_name(0)); import os; print('cpus', os.cpu_count())" > $OUT/env.txt 2>&1
 echo "== pytest -m gpu"
-timeout 1500 python -m pytest tests -m gpu -q -x -s 2>&1 | grep -v "amdgpu.ids" > $OUT/pytest_gpu_full.txt
+timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "amdgpu.ids" > $OUT/pytest_gpu_full.txt
 grep -E "^encoder |retrieval agreement|sharded selftest|ids==one-index|passed|failed|Error|error" $OUT/pytest_gpu_full.txt | cut -c1-600 | tail -60
 tail -3 $OUT/pytest_gpu_full.txt
 echo "== smoke"

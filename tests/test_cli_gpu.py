@@ -14,9 +14,10 @@ torch = pytest.importorskip("torch")
 
 def encode_np(tok, a, b, max_length, pad):
     """numpy (ids, mask) of one text / pair under the reference's 2.11 contract (data.encode_pairs_2_11; for a single text the
-    tokenizer's own call)."""
+    tokenizer's own call on the text with 2.11's prefix space, restated here: " " + text unless it starts with whitespace)."""
     from multihop_dense_retrieval_amd import data
     if b is None:
+        a = " " + a if a and not a[0].isspace() else a
         e = tok([a], max_length=max_length, padding="max_length" if pad else False, truncation=True, return_tensors="np")
         return e["input_ids"].astype(np.int64), e["attention_mask"].astype(np.int64)
     ids, mask = data.encode_pairs_2_11(tok, [a], [b], max_length, pad)

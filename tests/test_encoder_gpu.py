@@ -30,8 +30,11 @@ TOL = {"tiny": (6e-3, 1.2e-3), "base": (1.2e-2, 2e-3)}
 #   (b) mean |HIP - o1ops| <= B * e_regime : and closer to the O1 outputs than O1 is to fp32 -- sharp on the SHALLOW full-width stack
 #       (wide2: one full layer + the CLS layer on roberta-base tile shapes), where a kernel defect of ~3e-4 mean shows; at depth 12
 #       two correct implementations are already 0.8 apart, so there the bar only bounds the decorrelation.
-# measured (round 3, MI355X): see the printed lines in profiles/r03_*pytest_gpu.txt
-O1_BARS = {"tiny": (1.25, 0.90), "wide2": (1.25, 0.90), "base": (1.20, 1.05)}
+# measured (round 3, MI355X, profiles/r03a_encoder_o1_distances.txt), residual_fp32 = 1 / 0:
+#   (a) HIP-fp32 / e_regime   tiny 1.01-1.06 / 1.05-1.12   wide2 0.95-1.01 / 1.03   base 0.98-1.02 / 0.98-0.99
+#   (b) HIP-o1ops / e_regime  tiny 0.64-0.68 / 0.82-0.86   wide2 0.67-0.71 / 0.75   base 0.76-0.78 / 0.77-0.82
+# i.e. the HIP encoder sits where a second correct O1 implementation sits (the CPU restatement vs the hooked reference: 0.28-0.80).
+O1_BARS = {"tiny": (1.15, 0.80), "wide2": (1.10, 0.80), "base": (1.08, 0.88)}
 
 
 def build(geom, seed, cls=None, residual_fp32=None):
@@ -88,7 +91,7 @@ def test_distance_to_the_operand_rounded_reference(golden, tag, name, residual_f
           f"HIP-o1lit mean {dlit.mean():.3e} max {dlit.max():.3e}")
     A, B = O1_BARS[tag]
     if not residual_fp32:  # one more fp16 rounding per LayerNorm than apex O1 performs (the default, faster mode): reported, looser
-        A, B = A + 0.15, B + 0.15
+        A, B = A + 0.10, B + 0.10
     assert d32.mean() <= A * e_regime, (d32.mean(), e_regime)
     assert dops.mean() <= B * e_regime, (dops.mean(), e_regime)
     assert dops.max() <= 4.0 * np.abs(ops - f32).max()

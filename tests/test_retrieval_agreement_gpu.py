@@ -90,3 +90,5 @@ def test_top1_and_top4_ids_agree_with_fp64_reference_embeddings(residual_fp32):
         # questions slack: 2-10 questions of these samples)
         assert r["emb_mean_abs_err"] <= 1.15 * r["o1_regime_emb_mean_abs_err"], (name, r)
         assert r["top1_agreement"] >= r["o1_regime_top1_agreement_with_exact"] - 0.01, (name, r)
+        # measured (round 3): HIP vs exact 98.5-99.3 %, apex-O1 regime vs exact 98.0-99.3 %, HIP vs the O1 regime's embeddings 99.5-99.6 %
+        assert r["hip_top1_agreement_with_o1_regime"] >= 0.985, (name, r)
