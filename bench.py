@@ -95,6 +95,8 @@ def parse():
                     help="one batch at a time (hop-1 encode, search, hop-2 encode, search as four dependent stages). Default: the "
                          "software-pipelined loop -- hop 2 of batch i beside hop 1 of batch i+1: two concurrent encoder forwards (two lanes / streams) + one fused corpus pass")
     ap.add_argument("--no-sequential", action="store_true", help="pipelined run: do not append the sequential sub-result")
+    ap.add_argument("--no-anisotropic", action="store_true", help="do not append the anisotropic-corpus MIPS sub-result (N = 1, beam 1)")
+    ap.add_argument("--aniso-m", type=float, nargs="*", default=[20.0, 200.0], help="norms m of the common component of the anisotropic sub-result")
     ap.add_argument("--dump-ids", default=None, help="rank 0 writes the last step's hop-1 / hop-2 ids and scores to this .npz (tests)")
     ap.add_argument("--no-strong", action="store_true", help="N>1, weak scaling: do not append the strong-scaling sub-result")
     ap.add_argument("--mode", choices=["retrieval", "encode-corpus"], default="retrieval",
@@ -200,6 +202,60 @@ def verify_full_size(out, lo, hi, n_total, d, device, beam, bf16_rows=False):
         res[f"hop{hop}_ok"] = bool(exact_err <= 1e-3 and beaten <= 2e-3 and bool((same | near).all()) and rel32 <= 1e-2)
     res["full_size_exact"] = bool(res["hop1_ok"] and res["hop2_ok"])
     return res
+
+
+def anisotropic_subresult(args, device):
+    """The MIPS of the headline (5M x 768, beam 1, 100 / 200 queries per call) on ANISOTROPIC rows -- m u + N(0, 1) for a fixed unit
+    vector u, m = args.aniso_m (dense-retrieval embeddings share a large common component; iid rows are the easy case for any
+    screening bound): ms per search, which tier decided, candidates, ids against a brute-force fp32 matmul over all rows. The int8
+    plane is centred / scaled per column (csrc/mdr_mips.hip col_sum_kernel), so this should read like the iid numbers."""
+    from multihop_dense_retrieval_amd import index as mdr_index
+    N, d = args.rows, args.dim
+    g = torch.Generator(device=device).manual_seed(777)
+    u = torch.randn(d, generator=g, device=device)
+    u = u / u.norm()
+    out = {}
+    for m in args.aniso_m:
+        idx = mdr_index.IndexFlatIP(d, device=device)
+        idx.reserve(N)
+        nch = -(-N // CHUNK_ROWS)
+        planted = None
+        for c in range(nch):
+            x = corpus_chunk(0, c, CHUNK_ROWS, d, device)[: min(CHUNK_ROWS, N - c * CHUNK_ROWS)] + m * u
+            if c == 0:
+                planted = x[torch.arange(200, device=device) * 1009 % x.shape[0]].clone()
+            idx.add(x)
+            del x
+        res = {}
+        for nq in (100, 200):
+            q = (planted[:nq] + 0.05 * corpus_chunk(5, nq, nq, d, device)).contiguous()
+            D, I = idx.search_device(q, 1)
+            torch.cuda.synchronize()
+            t = idx.telemetry(nq, 1)
+            for _ in range(3):
+                idx.search_device(q, 1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                idx.search_device(q, 1)
+            e1.record()
+            torch.cuda.synchronize()
+            # brute force (fp32 matmul, all rows)
+            bs = torch.full((nq,), -float("inf"), device=device)
+            bi = torch.full((nq,), -1, dtype=torch.int64, device=device)
+            for c in range(nch):
+                x = corpus_chunk(0, c, CHUNK_ROWS, d, device)[: min(CHUNK_ROWS, N - c * CHUNK_ROWS)] + m * u
+                s_, a_ = (q @ x.T).max(1)
+                better = s_ > bs
+                bs, bi = torch.where(better, s_, bs), torch.where(better, a_ + c * CHUNK_ROWS, bi)
+                del x
+            res[f"nq{nq}"] = {"ms_per_search": round(e0.elapsed_time(e1) / 10, 4), "kernel": idx.last_kernel(), "int8_tier_decided": bool(t["i8_tier"] and not t["i8_overflow"]),
+                              "exact_fallback_ran": bool(t["fallback"]), "candidates_emitted": t["candidates"], "candidates_rescored": t["i8_refined"],
+                              "top1_id_agreement_with_bruteforce": round(float((I[:, 0] == bi).float().mean()), 4)}
+        out[f"m={m:g}"] = res
+        del idx
+        torch.cuda.empty_cache()
+    return out
 
 
 def calls_nq(pipe):
@@ -509,6 +565,10 @@ def main():
         result["strong_scaling"] = {"value": round(B * args.steps / el_s, 2), "unit": "queries/s", "ms_per_step": round(el_s / args.steps * 1e3, 4),
                                     "global_batch": B, "note": "one batch of --batch questions for all ranks: encoder slices split over ranks + all-gather"}
 
+    # (part of the full default line only: diagnostic invocations -- --no-cpu-baseline / --no-verify / --no-encoder -- skip it)
+    if (rank == 0 and world == 1 and not args.no_anisotropic and args.beam == 1 and args.storage != "bf16" and d == 768
+            and not (args.no_cpu_baseline or args.no_verify or args.no_encoder)):
+        result["anisotropic"] = anisotropic_subresult(args, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, device, gpu_index=local)
     if rank == 0:

@@ -34,7 +34,8 @@ extern "C" {
 #define MDR_OK 0
 #define MDR_E_INVALID (-1)  /* bad argument (k < 1, k > MDR_KMAX, nq < 0, d unsupported, NULL ...) */
 #define MDR_E_HIP (-2)      /* a HIP runtime call failed; mdr_last_error() carries hipGetErrorString */
-#define MDR_E_RANGE (-3)    /* value not representable in the index storage (|x| > 32768 for F32X2H) */
+#define MDR_E_RANGE (-3)    /* a row value is non-finite (add() takes any finite fp32 like IndexFlatIP.add: F32X2H rows are stored times a
+                             * power of two fitted to the data) */
 #define MDR_E_WORKSPACE (-4) /* workspace too small: call the matching *_workspace_bytes first */
 #define MDR_E_STATE (-5)    /* handle in the wrong state (e.g. search on an empty encoder) */
 

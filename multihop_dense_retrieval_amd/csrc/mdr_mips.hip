@@ -101,10 +101,14 @@ __device__ inline unsigned short f32_to_bf16_rne(float x) {
 __device__ inline float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 
 // BF = false: F32X2H planes (fp16 hi + fp16 lo);  BF = true: one plane of bf16 values (dst_lo unused)
+// F32X2H rows are stored as x * 2^-E (xinv = 2^-E, exact) for ONE exponent E per index, chosen by add() so that the largest magnitude it
+// has seen sits near 2^9..2^10: fp16's 11 significant bits (22 with the lo plane) then cover the data whatever its absolute scale is --
+// rows of magnitude 1e-6 are not lost in fp16 subnormals, rows of magnitude 1e5 do not overflow -- and every score is multiplied
+// back by 2^E (exact) where it leaves the library. FAISS IndexFlatIP.add takes any finite fp32 (eval_mhop_retrieval.py:94,122).
 template <typename T, bool BF>
 __global__ void __launch_bounds__(256) convert_to_frag_kernel(const T* __restrict__ src, long long n_valid, long long n_total,
                                                               int d, long long row0, char* __restrict__ dst_hi, char* __restrict__ dst_lo,
-                                                              int* __restrict__ flags) {
+                                                              int* __restrict__ flags, float xinv) {
     const int gpr = d >> 3;
     const int nkb = d >> 5;
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,7 +127,9 @@ __global__ void __launch_bounds__(256) convert_to_frag_kernel(const T* __restric
                 if (!(fabsf(x) <= 3.0e38f)) bad = true;
                 hb[j] = f32_to_bf16_rne(x);
             } else {
-                if (!(fabsf(x) <= 32768.0f)) bad = true;
+                if (!(fabsf(x) <= 3.0e38f)) bad = true;
+                x *= xinv;
+                if (!(fabsf(x) <= 32768.0f)) bad = true;  // (cannot happen for finite x: add() fits E to the data first)
                 _Float16 hh = (_Float16)x;
                 float res = x - (float)hh;
                 h[j] = hh;
@@ -146,15 +152,41 @@ __global__ void __launch_bounds__(256) convert_to_frag_kernel(const T* __restric
 
 // one wave per row: flags[2] (as float bits) = max over rows of sum(x^2)   (non-negative floats order like ints)
 template <typename T>
-__global__ void __launch_bounds__(256) row_norm2_max_kernel(const T* __restrict__ src, long long n, int d, int* __restrict__ flags) {
+__global__ void __launch_bounds__(256) row_norm2_max_kernel(const T* __restrict__ src, long long n, int d, int* __restrict__ flags, float xinv) {
     const int lane = threadIdx.x & 63;
     long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
     float s = 0.f;
-    for (int c = lane; c < d; c += 64) { float x = load_as_f32<T>(src + r * (long long)d + c); s += x * x; }
+    for (int c = lane; c < d; c += 64) { float x = load_as_f32<T>(src + r * (long long)d + c) * xinv; s += x * x; }  // in STORED units (x 2^-E)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0 && s == s && __float_as_int(s) > flags[2]) atomicMax(flags + 2, __float_as_int(s));  // pre-check: one hot word
+}
+
+// flags[4] (as float bits) = max |x| over the rows an add() is about to take; a NaN / inf leaves a non-finite pattern there
+template <typename T>
+__global__ void __launch_bounds__(256) absmax_kernel(const T* __restrict__ src, long long count, int* __restrict__ flags) {
+    float m = 0.f;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        const float x = fabsf(load_as_f32<T>(src + i));
+        if (!(x <= 3.0e38f)) bad = true;
+        m = fmaxf(m, x);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicMax(flags + 4, 0x7F800000);  // +inf: "non-finite seen"
+    if ((threadIdx.x & 63) == 0 && __float_as_int(m) > flags[4]) atomicMax(flags + 4, __float_as_int(m));
+}
+// the stored planes times a power of two (the index exponent E grew): exact unless a value falls below fp16's range
+__global__ void __launch_bounds__(256) rescale_planes_kernel(char* __restrict__ hi, char* __restrict__ lo, long long n_vec8, float f) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_vec8) return;
+    half8 h = *(const half8*)(hi + i * 16), l = *(const half8*)(lo + i * 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h[j] = (_Float16)((float)h[j] * f); l[j] = (_Float16)((float)l[j] * f); }
+    *(half8*)(hi + i * 16) = h;
+    *(half8*)(lo + i * 16) = l;
 }
 
 // Query preparation, one wave per query row (rows >= nq are zero padding). Every query is PRE-SCALED by a power of two
@@ -173,7 +205,7 @@ __global__ void __launch_bounds__(256) row_norm2_max_kernel(const T* __restrict_
 template <bool BF>
 __global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restrict__ q, int nq, int nq_pad, int d, int* __restrict__ flags, float c,
                                                            char* __restrict__ qhi, char* __restrict__ qlo, float* __restrict__ bound,
-                                                           float* __restrict__ qscale) {
+                                                           float* __restrict__ qscale, float xs /* 2^E of the stored rows: folded into qscale */) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= nq_pad) return;
@@ -217,7 +249,7 @@ __global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restri
         }
     }
     if (lane == 0) {
-        qscale[i] = sc;
+        qscale[i] = sc * xs;
         bound[i] = i < nq ? c * (sqrtf(ss) * inv) * sqrtf(__int_as_float(flags[2])) * 1.0001f + 1e-4f : 0.f;
     }
 }
@@ -823,7 +855,7 @@ mips_screen32_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, c
 // reconstructed values of both planes, then a 16-lane butterfly. Every lane of the group returns the sum.
 template <bool BF>
 __device__ __forceinline__ float exact_dot16(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ qrow,
-                                             unsigned row, int sub) {
+                                             unsigned row, int sub, float xs /* 2^E: stored rows -> the caller's scale (exact) */) {
     const size_t base = ((size_t)(row >> 4) * nkb) * kFragBytes + (size_t)(row & 15) * 16;
     float acc = 0.f;
     for (int pc = sub; pc < nkb * 4; pc += 16) {  // piece = (k-block, 8-column group)
@@ -843,7 +875,7 @@ __device__ __forceinline__ float exact_dot16(const char* __restrict__ Xhi, const
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    return acc;
+    return acc * xs;
 }
 
 // exact re-scoring of the screen kernel's candidates: 16 lanes per (query, row);
@@ -851,7 +883,7 @@ __device__ __forceinline__ float exact_dot16(const char* __restrict__ Xhi, const
 template <bool BF>
 __global__ void __launch_bounds__(256)
 mips_refine_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, const u64* __restrict__ cand,
-                   const int* __restrict__ cand_cnt, u64* __restrict__ best, const int* __restrict__ run_if = nullptr) {
+                   const int* __restrict__ cand_cnt, u64* __restrict__ best, float xs, const int* __restrict__ run_if = nullptr) {
     if (run_if && *run_if == 0) return;
     const int n = cand_cnt[blockIdx.x];
     if (n == 0) return;
@@ -861,7 +893,7 @@ mips_refine_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, i
     for (int c = threadIdx.x >> 4; c < n; c += 16) {
         const u64 e = list[c];
         const unsigned qi = (unsigned)(e >> 32), row = (unsigned)e;
-        const float acc = exact_dot16<BF>(Xhi, Xlo, nkb, q + (size_t)qi * d, row, sub);
+        const float acc = exact_dot16<BF>(Xhi, Xlo, nkb, q + (size_t)qi * d, row, sub, xs);
         if (sub == 0) atomicMax(best + qi, make_key(acc, row));
     }
 }
@@ -1158,7 +1190,7 @@ template <bool BF>
 __global__ void __launch_bounds__(256)
 merge_screenk_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_cnt, int G, int k, const float* __restrict__ qbound,
                      const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, float* __restrict__ D,
-                     long long* __restrict__ I, long long id_offset, int* __restrict__ overflow, int qcap /* queries per group: list stride */) {
+                     long long* __restrict__ I, long long id_offset, int* __restrict__ overflow, int qcap /* queries per group: list stride */, float xs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     u64* keys = (u64*)lds;  // [kMergeKLds]
     __shared__ u64 surv[kSurvMax];
@@ -1217,7 +1249,7 @@ merge_screenk_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_
     const float* qrow = q + (size_t)ql * (nkb * 32);
     for (int c = tid >> 4; c < ns; c += 16) {
         const unsigned row = key_row(surv[c]);
-        const float acc = exact_dot16<BF>(Xhi, Xlo, nkb, qrow, row, sub);
+        const float acc = exact_dot16<BF>(Xhi, Xlo, nkb, qrow, row, sub, xs);
         if (sub == 0) surv[c] = make_key(acc, row);  // only this 16-lane group touches surv[c]
     }
     __syncthreads();
@@ -1238,7 +1270,7 @@ merge_screenk_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_
 template <bool BF>
 __global__ void __launch_bounds__(256)
 mips_generic_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, long long n_rows, int n_rb, int nkb, const float* __restrict__ q, int nq,
-                    u64* __restrict__ cand, int* __restrict__ cand_cnt, u64* __restrict__ cand_kth, int k, const int* __restrict__ run_if) {
+                    u64* __restrict__ cand, int* __restrict__ cand_cnt, u64* __restrict__ cand_kth, int k, const int* __restrict__ run_if, float xs) {
     __shared__ int lds_cnt[kGenericQ];
     if (run_if && *run_if == 0) return;
     const int lane = threadIdx.x & 63;
@@ -1283,7 +1315,7 @@ mips_generic_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 unsigned row = (unsigned)rb * 16u + 4u * g4 + r;
-                consider(acc[r], row, ((long long)row < n_rows) && q_valid, tau, my_list, lds_cnt + qlocal);
+                consider(acc[r] * xs, row, ((long long)row < n_rows) && q_valid, tau, my_list, lds_cnt + qlocal);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             wave_prune_if_needed<kGenericCap / 64, kGenericCap>(wave_lists, lds_cnt + wave * 16, k, lane, tau, false, nullptr);
@@ -1341,11 +1373,100 @@ __device__ inline int wave_sum_i(int v) {
     return v;
 }
 
-// one wave per row: lanes 0 .. d/16-1 quantise 16 consecutive columns each. stats[0] = max s_r, stats[1] = max s_r (L1(x8_r)/2 + d/4)
+// Centre of the int8 plane. Real embedding matrices are anisotropic (LayerNorm outputs share a bias vector and a few large, row-independent
+// coordinates): quantised as they are, one outlier coordinate sets every row scale s_r and the bounds widen by its size. Since
+//     q.x = q.(x - c) + q.c          and q.c is the same for every row of a query,
+// the plane stores x - c for a fixed vector c and the screen ranks rows by bounds on q.(x - c): identical ranking, bounds as tight as for
+// centred data. c = the column means of (at most the first 65536 rows of) the FIRST add(), frozen afterwards -- ANY fixed c is correct,
+// a good one is only faster. Where a centred bound meets an exact (uncentred) score -- the `known` seeds and the thresholds of
+// mips_refine8_kernel -- the per-query offset q.c (+ its fp32 rounding slack: qab[q][3]) is subtracted from the exact score first.
+// The same identity holds coordinate by coordinate for any positive weights w:  q.(x - c) = sum_i (q_i w_i) ((x_i - c_i) / w_i).  Outlier
+// coordinates of real embeddings are large but nearly CONSTANT across rows; with w_i = the column's standard deviation the plane stores
+// (x_i - c_i) / w_i ~ unit variance in every coordinate and the query enters as q_i w_i, so a query's own outlier coordinate (which would
+// otherwise set its quantisation step t for all 768 coordinates) shrinks to the size of the others. w is taken with c and frozen with it;
+// it is a power of two (exact scaling) clamped to [2^-12, 2^12] times the median-free reference 1 (a constant column gets w = 1).
+// One block per 64 columns; block (x, y): rows y, y + gridDim.y, ...; partial sums / sums of squares are combined with atomicAdd into
+// a zeroed buffer (sums[0..d) and sums[d..2d)).
+template <typename T>
+__global__ void __launch_bounds__(256) col_sum_kernel(const T* __restrict__ src, long long n, int d, float* __restrict__ sums) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rsub = threadIdx.x >> 6;
+    float a1 = 0.f, a2 = 0.f;
+    if (c < d)
+        for (long long r = (long long)blockIdx.y * 4 + rsub; r < n; r += (long long)gridDim.y * 4) {
+            const float x = load_as_f32<T>(src + r * (long long)d + c);
+            a1 += x;
+            a2 = fmaf(x, x, a2);
+        }
+    red[0][rsub][threadIdx.x & 63] = a1;
+    red[1][rsub][threadIdx.x & 63] = a2;
+    __syncthreads();
+    if (rsub == 0 && c < d) {
+        atomicAdd(sums + c, red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
+        atomicAdd(sums + d + c, red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+    }
+}
+// sums -> cw[0..d) = centre (column means), cw[d..2d) = 1 / w, cw[2d..3d) = w.
+// The quantisation steps are set by the LARGEST scaled coordinate on either side: s_r ~ max_i |x_i - c_i| / w_i for the rows and
+// t ~ max_i |q_i| w_i for a query, and the bound is about s_r |q w|_1 / 2 + t |(x - c) / w|_1 / 2. With A_i = std_i / ref (a column's spread
+// relative to the typical spread ref = RMS of the column stds) and B_i = (|c_i| + 3.5 std_i) / (3.5 ref) (how large a QUERY's coordinate is
+// expected to be there: queries are embeddings of the same kind as the rows), the weights that minimise X + Y = max_i A_i / w_i + max_i B_i w_i
+// are any w_i in [A_i / X, X / B_i] with X = Y = sqrt(max(1, max_i A_i B_i)); w_i = 1 wherever that interval contains 1 (isotropic
+// data: everywhere), the nearer end otherwise, rounded to a power of two (exact scaling) in 2^+-12. A large, nearly constant outlier
+// coordinate (A small, B large) is scaled DOWN so that the query's outlier shrinks while the rows' small spread there still resolves; a
+// dense common mean needs nothing on the row side (the centre removes it) and a little on the query side.
+// One block of 1024 threads (d <= 1024).
+__global__ void __launch_bounds__(1024) centre_finish_kernel(const float* __restrict__ sums, int d, float inv_n, float* __restrict__ cw) {
+    __shared__ float red[16];
+    __shared__ float bc;
+    const int i = threadIdx.x;
+    auto block_reduce = [&](float v, bool is_max) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const float u = __shfl_xor(v, o); v = is_max ? fmaxf(v, u) : v + u; }
+        __syncthreads();
+        if ((i & 63) == 0) red[i >> 6] = v;
+        __syncthreads();
+        if (i == 0) {
+            float t = red[0];
+            for (int k = 1; k < 16; ++k) t = is_max ? fmaxf(t, red[k]) : t + red[k];
+            bc = t;
+        }
+        __syncthreads();
+        return bc;
+    };
+    float mu = 0.f, var = 0.f;
+    if (i < d) {
+        mu = sums[i] * inv_n;
+        var = fmaxf(sums[d + i] * inv_n - mu * mu, 0.f);
+        if (!(fabsf(mu) <= 3.0e38f) || !(var <= 3.0e38f)) { mu = 0.f; var = 0.f; }  // (non-finite rows: the add is rejected anyway; keep c and w finite)
+    }
+    const float ref = sqrtf(block_reduce(var, false) / (float)d);
+    float A = 0.f, B = 0.f;
+    if (i < d && ref > 0.f) {
+        const float sd = sqrtf(var);
+        A = sd / ref;
+        B = (fabsf(mu) + 3.5f * sd) / (3.5f * ref);
+    }
+    const float X = sqrtf(fmaxf(1.f, block_reduce(A * B, true)));
+    if (i >= d) return;
+    float w = 1.f;
+    if (ref > 0.f) {
+        const float lo = A / X, hi = B > 0.f ? X / B : 3.0e38f;  // lo <= hi because A B <= X^2
+        const float wr = lo > 1.f ? lo : (hi < 1.f ? hi : 1.f);
+        int e = (int)rintf(log2f(fmaxf(wr, 1e-30f)));
+        e = e < -12 ? -12 : (e > 12 ? 12 : e);
+        w = ldexpf(1.f, e);
+    }
+    cw[i] = mu;
+    cw[d + i] = 1.f / w;
+    cw[2 * d + i] = w;
+}
+
+// one wave per row: lanes 0 .. d/16-1 quantise 16 consecutive columns each of x - centre. stats[0] = max s_r, stats[1] = max s_r (L1(x8_r)/2 + d/4)
 // (non-negative floats, kept as their bit patterns: they order like ints)
 template <typename T>
 __global__ void __launch_bounds__(256) convert_to_i8_kernel(const T* __restrict__ src, long long n, int d, long long row0, char* __restrict__ dst,
-                                                            int* __restrict__ stats) {
+                                                            int* __restrict__ stats, const float* __restrict__ centre) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
@@ -1355,7 +1476,7 @@ __global__ void __launch_bounds__(256) convert_to_i8_kernel(const T* __restrict_
     float mx = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        x[j] = on ? load_as_f32<T>(src + r * (long long)d + lane * 16 + j) : 0.f;
+        x[j] = on ? (load_as_f32<T>(src + r * (long long)d + lane * 16 + j) - centre[lane * 16 + j]) * centre[d + lane * 16 + j] : 0.f;  // (x - c) / w
         mx = fmaxf(mx, fabsf(x[j]));
     }
     mx = wave_max_f(mx);
@@ -1392,21 +1513,30 @@ __global__ void __launch_bounds__(256) convert_to_i8_kernel(const T* __restrict_
 
 // one wave per query row (rows >= nq: zero padding). q8: fragment-tiled like the corpus blocks (16 queries per block, NKB8 KiB
 // each); qab[i] = (t, alpha, beta, 0) with the 1e-3 inflation described above.
+// qab[i][3] = q.c + slack (c = the plane's centre): what is subtracted from an EXACT score of a row to get a valid lower bound of its
+// centred score q.(x - c). slack = 1e-4 sum|q_i c_i| + 2e-6 |q.c| covers the fp32 summation of q.c (768 terms) and the fp32 rounding of
+// x - c in convert_to_i8_kernel; the 1e-3 inflation of alpha / beta covers the rest as before.
 __global__ void __launch_bounds__(256) prep_queries_i8_kernel(const float* __restrict__ q, int nq, int nq_pad, int d, const int* __restrict__ stats,
-                                                              char* __restrict__ q8, f32x4* __restrict__ qab) {
+                                                              char* __restrict__ q8, f32x4* __restrict__ qab, const float* __restrict__ centre) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= nq_pad) return;
     const int nkb8 = d >> 6;
     const bool on = lane < (d >> 4) && i < nq;
     float x[16];
-    float mx = 0.f;
+    float mx = 0.f, qc = 0.f, qca = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         x[j] = on ? q[(size_t)i * d + lane * 16 + j] : 0.f;
+        const float cj = on ? centre[lane * 16 + j] : 0.f;
+        qc = fmaf(x[j], cj, qc);
+        qca = fmaf(fabsf(x[j]), fabsf(cj), qca);
+        x[j] *= on ? centre[2 * d + lane * 16 + j] : 0.f;  // q_i w_i (w a power of two: exact)
         mx = fmaxf(mx, fabsf(x[j]));
     }
     mx = wave_max_f(mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { qc += __shfl_xor(qc, o); qca += __shfl_xor(qca, o); }
     const bool fin = mx <= 3.0e38f;  // a non-finite query gets an infinite bound below: every row becomes a candidate, the lists overflow, the tiers behind decide
     const float t = mx > 0.f && fin ? mx / 127.f : 0.f;
     const float inv = mx > 0.f && fin ? 127.f / mx : 0.f;
@@ -1431,7 +1561,7 @@ __global__ void __launch_bounds__(256) prep_queries_i8_kernel(const float* __res
     }
     if (lane == 0) {
         const float s2 = __int_as_float(stats[1]);
-        f32x4 o = {t, 0.5f * t * (float)l1 * 1.001f, t * s2 * 1.001f, 0.f};
+        f32x4 o = {t, 0.5f * t * (float)l1 * 1.001f, t * s2 * 1.001f, qc + (1e-4f * qca + 2e-6f * fabsf(qc))};
         if (!fin) o = (f32x4){0.f, INFINITY, INFINITY, 0.f};
         qab[i] = o;
     }
@@ -1486,12 +1616,12 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
     if (q_valid) ab = qab[qlocal];
     float qt = ab[0], qa = ab[1], qb = ab[2];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    float known = -FLT_MAX;  // largest lower bound known for this lane's query
+    float known = -FLT_MAX;  // largest lower bound (of the CENTRED score q.(x - c)) known for this lane's query
     if (MODE == 1 && q_valid) {
         unsigned g = gmax[qlocal];
         if (g) known = unord32(g);
-        const u64 kb = best[q_base + qlocal];  // the exact score of a real row is a lower bound of the best score too
-        if (kb) known = fmaxf(known, key_score(kb));
+        const u64 kb = best[q_base + qlocal];  // the exact score of a real row, minus q.c (+ slack), is a lower bound of the best centred score too
+        if (kb) known = fmaxf(known, key_score(kb) - ab[3]);
     }
     // retire every register load before the loop (see mips_screen_kernel)
 #pragma unroll
@@ -1731,7 +1861,7 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
         unsigned g = gmax[qlocal];
         if (g) known = unord32(g);
         const u64 kb = best[q_base + qlocal];
-        if (kb) known = fmaxf(known, key_score(kb));
+        if (kb) known = fmaxf(known, key_score(kb) - ab[3]);  // exact score -> centred lower bound (see mips_screen8_kernel)
     }
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) asm volatile("" : "+v"(qf[sl]));
@@ -1908,13 +2038,13 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
 // which then only gathers the rows whose upper bound reaches an exact score (a handful per query instead of hundreds).
 __global__ void __launch_bounds__(256)
 mips_star8_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, const u64* __restrict__ gstar, int nq,
-                  u64* __restrict__ best) {
+                  u64* __restrict__ best, float xs) {
     const int qi = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (qi >= nq) return;
     const u64 key = gstar[qi];
     if (key == 0) return;
     const unsigned row = (unsigned)key;
-    const float acc = exact_dot16<false>(Xhi, Xlo, nkb, q + (size_t)qi * (nkb * 32), row, sub);
+    const float acc = exact_dot16<false>(Xhi, Xlo, nkb, q + (size_t)qi * (nkb * 32), row, sub, xs);
     if (sub == 0) atomicMax(best + qi, make_key(acc, row));
 }
 
@@ -1923,7 +2053,8 @@ mips_star8_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, in
 // the tier then declares itself overflowed.
 __global__ void __launch_bounds__(256)
 mips_refine8_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, int nkb, const float* __restrict__ q, const u64* __restrict__ cand,
-                    const int* __restrict__ cand_cnt, const unsigned* __restrict__ gmax, u64* __restrict__ best, int* __restrict__ ctl8, int limit) {
+                    const int* __restrict__ cand_cnt, const unsigned* __restrict__ gmax, u64* __restrict__ best, int* __restrict__ ctl8, int limit,
+                    const f32x4* __restrict__ qab /* [3] = q.c + slack: exact score -> centred units (the candidates' bounds are centred) */, float xs) {
     if (ctl8[0] || ctl8[3] > limit) {
         if (blockIdx.x == 0 && threadIdx.x == 0) ctl8[0] = 1;
         return;
@@ -1939,8 +2070,14 @@ mips_refine8_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, 
     // so the lowest id still wins ties). (Reading `best` itself per candidate -- 4e5 uncached loads of 200 hot words -- doubled the
     // kernel's time.)
     __shared__ unsigned thr[32];
+    __shared__ float qoff[32];
     const unsigned qb32 = (unsigned)(list[0] >> 48) & ~31u;
-    if (threadIdx.x < 32) thr[threadIdx.x] = (unsigned)(best[qb32 + threadIdx.x] >> 48);
+    if (threadIdx.x < 32) {
+        const u64 kb = best[qb32 + threadIdx.x];
+        const float off = qab[qb32 + threadIdx.x][3];
+        qoff[threadIdx.x] = off;
+        thr[threadIdx.x] = kb ? ord32(key_score(kb) - off) >> 16 : 0u;  // (truncation rounds the threshold DOWN: safe)
+    }
     __syncthreads();
     int kept = 0;
     for (int c = threadIdx.x >> 4; c < n; c += 16) {
@@ -1948,10 +2085,10 @@ mips_refine8_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, 
         const unsigned qi = (unsigned)(e >> 48), u16 = (unsigned)(e >> 32) & 0xFFFFu, row = (unsigned)e;
         if (u16 < (gmax[qi] >> 16)) continue;  // U < final max L: cannot be the best row
         if (u16 < thr[qi & 31]) continue;
-        const float acc = exact_dot16<false>(Xhi, Xlo, nkb, q + (size_t)qi * d, row, sub);
+        const float acc = exact_dot16<false>(Xhi, Xlo, nkb, q + (size_t)qi * d, row, sub, xs);
         if (sub == 0) {
             atomicMax(best + qi, make_key(acc, row));
-            atomicMax(&thr[qi & 31], ord32(acc) >> 16);
+            atomicMax(&thr[qi & 31], ord32(acc - qoff[qi & 31]) >> 16);
             ++kept;
         }
     }
@@ -2118,6 +2255,11 @@ struct mdr_index {
     char* hi = nullptr;      // fragment-tiled planes, cap_rows * d * 2 bytes each
     char* lo = nullptr;
     char* i8 = nullptr;      // int8 screening plane (F32X2H storage, d = 768): cap_rows / 32 super-blocks of i8_sb_bytes(d / 64), see mips_screen8_kernel
+    float* centre = nullptr; // [3 d] c | 1/w | w: centre and per-column scale of the int8 plane (col_sum_kernel), (0, 1, 1) until the first add() sets
+                             // them, frozen afterwards; [3 d .. 5 d) scratch for the column sums
+    bool centre_set = false;
+    int xexp = 0;            // F32X2H: the planes hold x * 2^-xexp (see convert_to_frag_kernel); fitted to the data by add(), grown by a rescale
+    bool xexp_set = false;
     int* flags = nullptr;    // device ints: [0] range error seen by add(), [1] same for queries (ignored), [2] max row |x|^2 (float bits),
                              // [8], [9] int8 tier: max row scale, max s_r (L1(x8_r)/2 + d/4) (float bits)
     void* stage = nullptr;   // device staging for host-sourced add()
@@ -2130,6 +2272,8 @@ namespace {
 
 
 size_t plane_bytes_per_row(const mdr_index* h) { return (size_t)h->d * 2; }
+float row_unscale(const mdr_index* h) { return ldexpf(1.f, h->xexp); }   // 2^E: stored rows -> the caller's scale
+float row_scale_inv(const mdr_index* h) { return ldexpf(1.f, -h->xexp); }  // 2^-E
 long long pad32(long long n) { return (n + 31) / 32 * 32; }
 
 // the int8 screening plane exists for the storage / dimension the k = 1 screen path serves; MDR_MIPS_I8=0 (read at index creation) leaves it out
@@ -2157,6 +2301,12 @@ int grow(mdr_index* h, long long need_rows, hipStream_t st) {
         MDR_HIP_TRY(hipMemsetAsync(planes[i] + used, 0, nbytes - used, st));
     }
     char* n8 = nullptr;
+    if (wants_i8(h) && !h->centre) {
+        MDR_HIP_TRY(hipMalloc((void**)&h->centre, (size_t)h->d * 5 * 4));
+        float init[3 * 1024];  // d <= 1024: c = 0, 1/w = 1, w = 1 until the first add() measures them
+        for (int i = 0; i < 3 * h->d; ++i) init[i] = i < h->d ? 0.f : 1.f;
+        MDR_HIP_TRY(hipMemcpy(h->centre, init, (size_t)h->d * 3 * 4, hipMemcpyHostToDevice));
+    }
     if (wants_i8(h)) {
         const size_t sbb = i8_sb_bytes(h->d / 64), nb8 = (size_t)(ncap / 32 + 1) * sbb, used8 = (size_t)(pad32(h->ntotal) / 32) * sbb;  // + 1: the wide kernel's stages are super-block pairs
         MDR_HIP_TRY(hipMalloc((void**)&n8, nb8));
@@ -2176,30 +2326,91 @@ int grow(mdr_index* h, long long need_rows, hipStream_t st) {
 
 template <typename T>
 int launch_convert(bool bf, const T* src_dev, long long n_valid, long long n_total, int d, long long row0, char* dst_hi, char* dst_lo, int* flags,
-                   hipStream_t st) {
+                   float xinv, hipStream_t st) {
     long long threads = n_total * (d / 8);
     if (threads == 0) return MDR_OK;
     long long blocks = (threads + 255) / 256;
     if (bf)
-        hipLaunchKernelGGL((convert_to_frag_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, st, src_dev, n_valid, n_total, d, row0, dst_hi, dst_lo, flags);
+        hipLaunchKernelGGL((convert_to_frag_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, st, src_dev, n_valid, n_total, d, row0, dst_hi, dst_lo, flags, 1.0f);
     else
-        hipLaunchKernelGGL((convert_to_frag_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st, src_dev, n_valid, n_total, d, row0, dst_hi, dst_lo, flags);
+        hipLaunchKernelGGL((convert_to_frag_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st, src_dev, n_valid, n_total, d, row0, dst_hi, dst_lo, flags, xinv);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }
 
+constexpr long long kCentreRows = 65536;  // rows of the first add() the int8 plane's centre is averaged over
+
 template <typename T>
 int launch_add(mdr_index* h, const T* src_dev, long long n, long long row0, hipStream_t st) {
-    int rc = launch_convert(h->storage == MDR_STORE_BF16, src_dev, n, n, h->d, row0, h->hi, h->lo, h->flags, st);
+    const float xinv = h->storage == MDR_STORE_BF16 ? 1.0f : row_scale_inv(h);
+    int rc = launch_convert(h->storage == MDR_STORE_BF16, src_dev, n, n, h->d, row0, h->hi, h->lo, h->flags, xinv, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(row_norm2_max_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src_dev, n, h->d, h->flags);
-    if (h->i8 && n > 0)
-        hipLaunchKernelGGL(convert_to_i8_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src_dev, n, h->d, row0, h->i8, h->flags + 8);
+    hipLaunchKernelGGL(row_norm2_max_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src_dev, n, h->d, h->flags, xinv);
+    if (h->i8 && n > 0) {
+        if (!h->centre_set) {  // the first rows this index ever sees define the centre of its int8 plane (any fixed vector is correct)
+            const long long nc = n < kCentreRows ? n : kCentreRows;
+            float* sums = h->centre + 3 * (size_t)h->d;
+            MDR_HIP_TRY(hipMemsetAsync(sums, 0, (size_t)h->d * 8, st));
+            const unsigned gy = (unsigned)((nc + 3) / 4 < 256 ? (nc + 3) / 4 : 256);
+            hipLaunchKernelGGL(col_sum_kernel<T>, dim3((unsigned)((h->d + 63) / 64), gy), dim3(256), 0, st, src_dev, nc, h->d, sums);
+            hipLaunchKernelGGL(centre_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)sums, h->d, 1.0f / (float)nc, h->centre);
+            h->centre_set = true;
+        }
+        hipLaunchKernelGGL(convert_to_i8_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src_dev, n, h->d, row0, h->i8, h->flags + 8,
+                           (const float*)h->centre);
+    }
     MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
+__global__ void scale_flag_float_kernel(int* __restrict__ flag, float f) { *flag = __float_as_int(__int_as_float(*flag) * f); }
+
+// Fit the index exponent E (planes hold x * 2^-E) to the rows about to be converted; rows [0, row0) are already stored. Synchronises.
+template <typename T>
+int fit_exponent(mdr_index* h, const T* src_dev, long long n, long long row0, hipStream_t st) {
+    if (h->storage == MDR_STORE_BF16 || n == 0) return MDR_OK;
+    MDR_HIP_TRY(hipMemsetAsync(h->flags + 4, 0, sizeof(int), st));
+    const long long count = n * (long long)h->d;
+    const unsigned blocks = (unsigned)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+    hipLaunchKernelGGL(absmax_kernel<T>, dim3(blocks), dim3(256), 0, st, src_dev, count, h->flags);
+    MDR_HIP_TRY(hipGetLastError());
+    int bits = 0;
+    MDR_HIP_TRY(hipMemcpyAsync(&bits, h->flags + 4, sizeof(int), hipMemcpyDeviceToHost, st));
+    MDR_HIP_TRY(hipStreamSynchronize(st));
+    float m;
+    memcpy(&m, &bits, 4);
+    if (!(m <= 3.0e38f)) return set_error(MDR_E_RANGE, "add(): a value is non-finite; rows were not added");
+    if (m == 0.f) return MDR_OK;
+    int e = 0;
+    (void)frexpf(m, &e);           // m in [2^(e-1), 2^e)
+    const int target = e - 10;     // m * 2^-target in [2^9, 2^10): headroom of 2^5 before fp16 overflows
+    if (!h->xexp_set) {
+        h->xexp = target;
+        h->xexp_set = true;
+        return MDR_OK;
+    }
+    if (e - h->xexp > 15) {        // m * 2^-E >= 2^15 would not fit: grow E and shrink what is stored by the same power of two (exact)
+        const float f = ldexpf(1.f, h->xexp - target);
+        const long long n_vec8 = (row0 + 15) / 16 * 16 * (long long)h->d / 8;
+        if (n_vec8 > 0) {
+            hipLaunchKernelGGL(rescale_planes_kernel, dim3((unsigned)((n_vec8 + 255) / 256)), dim3(256), 0, st, h->hi, h->lo, n_vec8, f);
+            hipLaunchKernelGGL(scale_flag_float_kernel, dim3(1), dim3(1), 0, st, h->flags + 2, f * f);  // max row |x|^2 in stored units
+            MDR_HIP_TRY(hipGetLastError());
+        }
+        h->xexp = target;
+    }
     return MDR_OK;
 }
 
 int add_any(mdr_index* h, const void* src_dev, int dtype, long long n, long long row0, hipStream_t st) {
+    int rc = MDR_OK;
+    switch (dtype) {  // (before anything is written: a non-finite value rejects the rows here)
+        case MDR_DT_F32: rc = fit_exponent(h, (const float*)src_dev, n, row0, st); break;
+        case MDR_DT_BF16: rc = fit_exponent(h, (const unsigned short*)src_dev, n, row0, st); break;
+        case MDR_DT_F16: rc = fit_exponent(h, (const _Float16*)src_dev, n, row0, st); break;
+        default: break;
+    }
+    if (rc) return rc;
     switch (dtype) {
         case MDR_DT_F32: return launch_add(h, (const float*)src_dev, n, row0, st);
         case MDR_DT_BF16: return launch_add(h, (const unsigned short*)src_dev, n, row0, st);
@@ -2320,7 +2531,7 @@ int run_generic(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
         MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.Gg * kGenericQ * 4, st));
         MDR_HIP_TRY(hipMemsetAsync(kth, 0, (size_t)p.Gg * kGenericQ * 8, st));
         hipLaunchKernelGGL((mips_generic_kernel<BF>), dim3(p.Gg), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, (long long)h->ntotal, n_rb, h->nkb,
-                           q_dev + (size_t)q0 * h->d, nqg, cand, cnt, kth, k, run_if);
+                           q_dev + (size_t)q0 * h->d, nqg, cand, cnt, kth, k, run_if, row_unscale(h));
         hipLaunchKernelGGL(merge_lists_kernel, dim3(nqg), dim3(256), 0, st, (const u64*)cand, (const int*)cnt, (const u64*)kth, p.Gg, kGenericQ, kGenericCap,
                            k, D_dev + (size_t)q0 * k, I_dev + (size_t)q0 * k, id_offset, run_if, (const float*)nullptr);
         MDR_HIP_TRY(hipGetLastError());
@@ -2355,7 +2566,7 @@ int run_screen(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, 
         hipLaunchKernelGGL((mips_screen_kernel<NKB, 1, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
                            (const float*)(bound + (size_t)gi * kStreamQ), nqg, gi * kStreamQ, gmax + (size_t)gi * kStreamQ, scand, wave_cnt, sctl, run_if);
         hipLaunchKernelGGL((mips_refine_kernel<BF>), dim3(p.G * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
-                           (const u64*)scand, (const int*)wave_cnt, best, run_if);
+                           (const u64*)scand, (const int*)wave_cnt, best, row_unscale(h), run_if);
         MDR_HIP_TRY(hipGetLastError());
     }
     return MDR_OK;
@@ -2380,16 +2591,17 @@ int run_screen8(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
     MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
     MDR_HIP_TRY(hipMemsetAsync(gstar, 0, (size_t)nq_pad * 8, st));
     MDR_HIP_TRY(hipMemsetAsync(ctl8, 0, 256, st));
-    hipLaunchKernelGGL(prep_queries_i8_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)(h->flags + 8), q8, qab);
+    hipLaunchKernelGGL(prep_queries_i8_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)(h->flags + 8), q8, qab,
+                       (const float*)h->centre);
     hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 0, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
                        (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar, (const u64*)best);
     // the sample pass's best-lower-bound rows, re-scored exactly: a first `known` that is up to 2 B tighter than their lower bounds
-    hipLaunchKernelGGL(mips_star8_kernel, dim3((nq + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)gstar, nq, best);
+    hipLaunchKernelGGL(mips_star8_kernel, dim3((nq + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)gstar, nq, best, row_unscale(h));
     hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 1, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
                        (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar, (const u64*)best);
-    hipLaunchKernelGGL(mips_star8_kernel, dim3((nq + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)gstar, nq, best);
+    hipLaunchKernelGGL(mips_star8_kernel, dim3((nq + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)gstar, nq, best, row_unscale(h));
     hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8 * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
-                       (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nq);
+                       (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nq, (const f32x4*)qab, row_unscale(h));
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }
@@ -2422,7 +2634,7 @@ int run_screen32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
         hipLaunchKernelGGL((mips_screen32_kernel<NKB, 1, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
                            (const float*)(bound + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, sctl, run_if);
         hipLaunchKernelGGL((mips_refine_kernel<BF>), dim3(p.G * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
-                           (const u64*)scand, (const int*)wave_cnt, best, run_if);
+                           (const u64*)scand, (const int*)wave_cnt, best, row_unscale(h), run_if);
         MDR_HIP_TRY(hipGetLastError());
     }
     return MDR_OK;
@@ -2448,7 +2660,8 @@ int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
     MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
     MDR_HIP_TRY(hipMemsetAsync(gstar, 0, (size_t)nq_pad * 8, st));
     MDR_HIP_TRY(hipMemsetAsync(ctl8, 0, 256, st));
-    hipLaunchKernelGGL(prep_queries_i8_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)(h->flags + 8), q8, qab);
+    hipLaunchKernelGGL(prep_queries_i8_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)(h->flags + 8), q8, qab,
+                       (const float*)h->centre);
     for (int gi = 0; gi < ngroups; ++gi) {
         const int nqg = nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ;
         const char* qg = q8 + (size_t)gi * kWideQ * h->d;
@@ -2457,14 +2670,14 @@ int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
                            (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8, gstar + (size_t)gi * kWideQ,
                            (const u64*)best);
         hipLaunchKernelGGL(mips_star8_kernel, dim3((nqg + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb,
-                           q_dev + (size_t)gi * kWideQ * h->d, (const u64*)(gstar + (size_t)gi * kWideQ), nqg, best + (size_t)gi * kWideQ);
+                           q_dev + (size_t)gi * kWideQ * h->d, (const u64*)(gstar + (size_t)gi * kWideQ), nqg, best + (size_t)gi * kWideQ, row_unscale(h));
         hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 1, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
                            (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8, gstar + (size_t)gi * kWideQ,
                            (const u64*)best);
         hipLaunchKernelGGL(mips_star8_kernel, dim3((nqg + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb,
-                           q_dev + (size_t)gi * kWideQ * h->d, (const u64*)(gstar + (size_t)gi * kWideQ), nqg, best + (size_t)gi * kWideQ);
+                           q_dev + (size_t)gi * kWideQ * h->d, (const u64*)(gstar + (size_t)gi * kWideQ), nqg, best + (size_t)gi * kWideQ, row_unscale(h));
         hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8w * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
-                           (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nqg);
+                           (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nqg, (const f32x4*)qab, row_unscale(h));
         MDR_HIP_TRY(hipGetLastError());
     }
     return MDR_OK;
@@ -2506,7 +2719,7 @@ int run_screenk(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
                            (const float*)tg, nqg, cand, cnt, k, sctl);
         hipLaunchKernelGGL((merge_screenk_kernel<BF>), dim3(nqg), dim3(256), merge_lds, st, (const u64*)cand, (const int*)cnt, p.G, k, bg, (const char*)h->hi,
                            (const char*)h->lo, h->nkb, q_dev + (size_t)gi * kStreamQ * h->d, D_dev + (size_t)gi * kStreamQ * k,
-                           I_dev + (size_t)gi * kStreamQ * k, id_offset, sctl, kStreamQ);
+                           I_dev + (size_t)gi * kStreamQ * k, id_offset, sctl, kStreamQ, row_unscale(h));
         MDR_HIP_TRY(hipGetLastError());
     }
     return MDR_OK;
@@ -2546,7 +2759,7 @@ int run_screenk32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_de
                            (const float*)tg, nqg, cand, cnt, k, sctl);
         hipLaunchKernelGGL((merge_screenk_kernel<BF>), dim3(nqg), dim3(256), merge_lds, st, (const u64*)cand, (const int*)cnt, p.G, k, bg, (const char*)h->hi,
                            (const char*)h->lo, h->nkb, q_dev + (size_t)gi * kWideQ * h->d, D_dev + (size_t)gi * kWideQ * k,
-                           I_dev + (size_t)gi * kWideQ * k, id_offset, sctl, kWideQ);
+                           I_dev + (size_t)gi * kWideQ * k, id_offset, sctl, kWideQ, row_unscale(h));
         MDR_HIP_TRY(hipGetLastError());
     }
     return MDR_OK;
@@ -2587,6 +2800,7 @@ int mdr_index_free(mdr_index* h) {
     if (h->hi) (void)hipFree(h->hi);
     if (h->lo) (void)hipFree(h->lo);
     if (h->i8) (void)hipFree(h->i8);
+    if (h->centre) (void)hipFree(h->centre);
     if (h->flags) (void)hipFree(h->flags);
     if (h->stage) (void)hipFree(h->stage);
     delete h;
@@ -2612,6 +2826,7 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
     int rc = grow(h, h->ntotal + n, st);
     if (rc) return rc;
     int before[16] = {0};  // [0..3] range / query / norm flags, [8..9] the int8 tier's row statistics: all restored when the rows are rejected
+    const bool centre_was_set = h->centre_set;
     MDR_HIP_TRY(hipMemcpyAsync(before, h->flags, sizeof(before), hipMemcpyDeviceToHost, st));
     MDR_HIP_TRY(hipStreamSynchronize(st));
     const size_t row_src = (size_t)h->d * elem_size(src_dtype);
@@ -2644,8 +2859,8 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
         // roll back: the rows stay invisible (ntotal unchanged), the norm bound returns to its previous value
         MDR_HIP_TRY(hipMemcpyAsync(h->flags, before, sizeof(before), hipMemcpyHostToDevice, st));
         MDR_HIP_TRY(hipStreamSynchronize(st));
-        return set_error(MDR_E_RANGE, is_bf16(h) ? "add(): a value is non-finite; rows were not added"
-                                                 : "add(): a value is non-finite or |x| > 32768, not representable in F32X2H storage; rows were not added");
+        h->centre_set = centre_was_set;  // a centre taken from rejected rows is forgotten: the next accepted add() defines it
+        return set_error(MDR_E_RANGE, "add(): a value is non-finite; rows were not added");
     }
     h->ntotal += n;
     return MDR_OK;
@@ -2727,9 +2942,10 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
         float* bound = (float*)(ws + p.off_bound);
         MDR_HIP_TRY(hipMemsetAsync(h->flags + 1, 0, sizeof(int), st));  // "a query of THIS call was non-finite" (telemetry)
         if (bf)
-            hipLaunchKernelGGL((prep_queries_kernel<true>), dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, h->flags, c, qhi, qlo, bound, qscale);
+            hipLaunchKernelGGL((prep_queries_kernel<true>), dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, h->flags, c, qhi, qlo, bound, qscale, 1.0f);
         else
-            hipLaunchKernelGGL((prep_queries_kernel<false>), dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, h->flags, c, qhi, qlo, bound, qscale);
+            hipLaunchKernelGGL((prep_queries_kernel<false>), dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, h->flags, c, qhi, qlo, bound, qscale,
+                               row_unscale(h));
         MDR_HIP_TRY(hipGetLastError());
     }
 

@@ -219,3 +219,39 @@ def test_int8_screen_bound_is_rigorous():
         assert (np.abs(true - approx) <= bound * 1.001 + 1e-300).all(), name
         if name == "gauss":  # ... and it is not vacuous: a few tenths of the score spread
             assert np.median(bound) < 1.0 * true.std()
+    # The plane is CENTRED (round 3): it stores x - c for a fixed vector c (fp32 subtraction), the bounds are bounds on q.(x - c), and an
+    # exact score e = q.x enters the centred domain as e - (q.c + slack), slack = 1e-4 sum|q_i c_i| + 2e-6 |q.c| (prep_queries_i8_kernel).
+    # Checked: (a) the interval still holds for the centred vectors, (b) e - (fl32(q.c) + slack) is a LOWER bound of the true centred
+    # score (so `known` / the refinement thresholds never cut a winner), (c) for rows with a large common component -- one outlier
+    # coordinate, a dense common mean -- centring shrinks the bound by about the size of that component.
+    for name, common in {"outlier-coordinate": np.eye(1, d, 7)[0] * 40.0, "dense-mean": np.full(d, 200.0 / np.sqrt(d))}.items():
+        x = rng.randn(300, d)
+        if name == "outlier-coordinate":
+            x[:, 7] *= 0.1  # large and nearly constant, as in real embeddings
+        x = (x + common).astype(np.float32)
+        q = (rng.randn(40, d) + (1.0 if name == "outlier-coordinate" else 0.2) * common).astype(np.float32)
+        c = x[:200].mean(0, dtype=np.float64).astype(np.float32)   # column means of the first rows, as add() takes them
+        sd = x[:200].std(0)
+        ref = np.sqrt((sd ** 2).mean())   # centre_finish_kernel: w_i in [A_i / X, X / B_i], 1 where possible, a power of two
+        A, B = sd / ref, (np.abs(c) + 3.5 * sd) / (3.5 * ref)
+        X = np.sqrt(max(1.0, (A * B).max()))
+        wr = np.where(A / X > 1, A / X, np.where(X / B < 1, X / B, 1.0))
+        w = np.exp2(np.clip(np.rint(np.log2(np.maximum(wr, 1e-30))), -12, 12)).astype(np.float32)
+        xc = ((x - c) / w).astype(np.float32)                      # fp32 subtraction + exact scaling, as convert_to_i8_kernel does it
+        x8, s = quant(xc)
+        q8, t = quant((q * w).astype(np.float32))                  # the query enters as q_i w_i: sum (q_i w_i) ((x_i - c_i) / w_i) = q.(x - c)
+        true_c = q.astype(np.float64) @ (x.astype(np.float64) - c.astype(np.float64)).T
+        approx = (q8 @ x8.T) * t[:, None] * s[None, :]
+        bound = t[:, None] * s[None, :] * (0.5 * np.abs(q8).sum(1)[:, None] + 0.5 * np.abs(x8).sum(1)[None, :] + 0.25 * d)
+        assert (np.abs(true_c - approx) <= bound * 1.001).all(), name
+        qc32 = np.zeros(len(q), np.float32)
+        for j in range(d):  # a sequential fp32 sum: the worst order the device could use
+            qc32 = (qc32 + q[:, j] * c[j]).astype(np.float32)
+        slack = 1e-4 * (np.abs(q.astype(np.float64)) * np.abs(c.astype(np.float64))).sum(1) + 2e-6 * np.abs(qc32)
+        exact = q.astype(np.float64) @ x.astype(np.float64).T
+        exact32 = exact * (1 + 3e-6 * np.sign(rng.randn(*exact.shape)))  # the fp32 re-scoring's own relative error (exact_dot16)
+        assert ((exact32 - (qc32.astype(np.float64) + slack)[:, None]) <= true_c + 1e-3 * bound).all(), name
+        x8u, su = quant(x)
+        q8u, tu = quant(q)
+        bound_u = tu[:, None] * su[None, :] * (0.5 * np.abs(q8u).sum(1)[:, None] + 0.5 * np.abs(x8u).sum(1)[None, :] + 0.25 * d)
+        assert np.median(bound_u) > 3.0 * np.median(bound), (name, np.median(bound_u), np.median(bound))
