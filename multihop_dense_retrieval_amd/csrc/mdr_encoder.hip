@@ -1093,19 +1093,23 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) v_rd[dt] = vkey * 128 + ((((dt * 2 + ((lr & 3) >> 1)) ^ vsw)) << 4) + (lr & 1) * 8;
 
+    // The Q fragments of a query block are plain register loads; they are issued BEFORE the K/V DMA of the first chunk and retired by the
+    // same vmcnt(0) wait, so that Q, K and V travel together (one memory round trip instead of two: round 2 waited for Q first, and the
+    // staging chain -- cu[b], Q, K/V, barrier -- was 33 of the kernel's 47 us). The second query block of a merged pair is fetched into
+    // the same registers as soon as the first block's S tiles no longer need them, under that block's softmax and PV product.
+    half8 qf[2];
+    auto load_q = [&](int sub_) __attribute__((always_inline)) {
+        const int qi_ = qb0 + sub_ * 128 + wave * 16 + lr;
+        const int qrow_ = qi_ < len ? qi_ : len - 1;
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const half8*)(qkv + (size_t)(start + qrow_) * H3 + h * 64 + ds * 32 + g * 8);
+    };
+    load_q(0);
     for (int sub = 0; sub < nsub; ++sub) {
     const int q0 = qb0 + sub * 128 + wave * 16;
     const bool wave_valid = q0 < len;  // waves past the sequence only help staging
     const int qi = q0 + lr;
     const bool qvalid = qi < len;
-    const int qrow = qvalid ? qi : len - 1;
-    half8 qf[2];
-#pragma unroll
-    for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const half8*)(qkv + (size_t)(start + qrow) * H3 + h * 64 + ds * 32 + g * 8);
-    // retire the Q loads before any DMA is in flight (a pending register load would make the compiler drain the DMA later)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int ds = 0; ds < 2; ++ds) asm volatile("" : "+v"(qf[ds]));
 
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 o[4];
@@ -1126,7 +1130,9 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
                 __builtin_amdgcn_global_load_lds(MDR_GPTR(src), MDR_LPTR(Ks + i * 1024), 16, 0, 0);
                 if (MDR_ATTN_ABL != 6) __builtin_amdgcn_global_load_lds(MDR_GPTR(src + H), MDR_LPTR(Vs + i * 1024), 16, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K / V pieces AND (first chunk) the Q loads issued in front of them
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) asm volatile("" : "+v"(qf[ds]));
             __syncthreads();
         }
         if (MDR_ATTN_ABL == 4 || MDR_ATTN_ABL >= 6) continue;
@@ -1159,6 +1165,7 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
                 for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, acc[r]);
             }
         }
+        if (merged && sub == 0) load_q(1);  // (merged: one chunk) the next block's Q, under this block's softmax and PV product
         cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
         const float m_new = fmaxf(m_run, cmax);  // finite: every chunk holds at least one valid key

@@ -161,3 +161,34 @@ def test_randomised_differential_against_the_exact_kernel(mdr, seed):
         q[: min(nq, 8)] = x[torch.randint(0, n, (min(nq, 8),), generator=g, device="cuda")] + 0.001 * q[: min(nq, 8)]
         q[0] = x[3]
     check(idx, q.contiguous())
+
+
+def test_more_than_128_queries_with_the_wide_kernels_switched_off():
+    """with MDR_MIPS_WIDE=0 (measurement knob: every call stays on the 128-queries-per-pass kernels) a k = 1 call with more
+    than 128 queries used to reach run_screen8, which serves ONE group of 128: queries 128.. came back as -1. The int8 tier is now
+    only planned for nq <= 128 or with the wide kernels; otherwise the fp16 screen, which loops over groups, decides. The variable is
+    read once per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import torch
+from multihop_dense_retrieval_amd import index as mi
+g = torch.Generator(device='cuda').manual_seed(5)
+xb = torch.randn((60000, 768), generator=g, device='cuda')
+q = torch.randn((300, 768), generator=g, device='cuda')
+q[:150] = xb[torch.arange(150, device='cuda') * 397] + 0.05 * q[:150]
+idx = mi.IndexFlatIP(768)
+idx.add(xb)
+D, I = idx.search_device(q, 1)
+kern = idx.last_kernel()
+idx.set_variant(2)
+De, Ie = idx.search_device(q, 1)
+assert torch.equal(I, Ie) and bool((I >= 0).all()), int((I != Ie).sum())
+assert float((D - De).abs().max()) <= 1e-3
+assert torch.equal(I[:150, 0], torch.arange(150, device='cuda') * 397)
+print('ok', kern)
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MDR_MIPS_WIDE="0"), capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "ok mips_screen_kernel<24,1>" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
