@@ -527,6 +527,10 @@ def main():
                                                       "`achieved` above counts both forwards' FLOPs over it, this entry's TFLOPs only the hop-2 forward's"}}
                         if pipe.pipelined else {})},
             "share_of_step": round(enc_ms / ms_per_step, 3),
+            "frac_of_sustained_mfma": round(ach / 1700.0, 4),
+            "sustained_mfma_note": "secondary: a register-only v_mfma_f32_16x16x32_f16 loop (scripts/ubench/mfma_peak.hip, two waves per SIMD) sustains 1.65-1.77 PFLOP/s "
+                                   "on RANDOM operands on this pool (2.35-2.41 on zeros): the chip clocks to its power limit (~1.7 GHz under a full matrix pipe); `frac` above is "
+                                   "against the nominal 2.5 PFLOP/s",
             "note": "executed FLOPs (masked tokens dropped, last layer CLS-only) / HIP-event stage time on the launch stream; peak = dense fp16 MFMA"}
     if hasattr(local, "telemetry") and calls_nq(pipe):  # which screening tier decided the LAST search of the timed region (test hook; outside it)
         t = local.telemetry(calls_nq(pipe), args.beam)
