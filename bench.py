@@ -28,7 +28,7 @@ Prints ONE JSON line on rank 0 with
 roofline.traffic is HBM bytes per search call from a separate `rocprofv3 --pmc FETCH_SIZE` pass (scripts/gpu_pmc_screen.sh;
 KB x 1024 x 2, the gfx950 correction of MI355X_MICROARCH.md), which cannot run inside this process: the measured ratio
 traffic / algorithmic bytes of each kernel family (profiles/pmc_traffic.json, written by that script with the hash of
-csrc/mdr_mips.hip at measurement time) is applied to this run's algorithmic bytes -- `traffic_fresh` is false and
+csrc/mdr_mips* at measurement time) is applied to this run's algorithmic bytes -- `traffic_fresh` is false and
 `traffic_source` says STALE when the kernel source has changed since -- or pass --pmc-traffic with a fresh measurement.
 """
 import argparse
@@ -49,15 +49,20 @@ CHUNK_ROWS = 250_000
 
 # measured HBM fetch bytes per search call / algorithmic bytes (N_pad * d * 4) per kernel family: profiles/pmc_traffic.json, written by
 # scripts/gpu_pmc_screen.sh (rocprofv3 --pmc FETCH_SIZE passes) together with the hash of csrc/mdr_mips.hip at measurement time.
-MIPS_SRC = os.path.join(ROOT, "multihop_dense_retrieval_amd", "csrc", "mdr_mips.hip")
+MIPS_SRC_GLOB = os.path.join(ROOT, "multihop_dense_retrieval_amd", "csrc", "mdr_mips*")  # mdr_mips.hip + the section files it includes
 
 
-def src_sha16(path=MIPS_SRC):
+def src_sha16(pattern=MIPS_SRC_GLOB):
+    """sha256[:16] over the MIPS kernel sources (sorted by name): what a counter measurement is valid for."""
+    import glob
     import hashlib
-    try:
-        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
-    except OSError:
+    h = hashlib.sha256()
+    files = sorted(glob.glob(pattern))
+    if not files:
         return None
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load_pmc_table():
@@ -283,7 +288,7 @@ def mips_roofline(pipe, local, args, d):
                 fresh = ent.get("csrc_sha16") is not None and ent.get("csrc_sha16") == now
                 src = (f"{ent['source']} (measured FETCH_SIZE x 2 / algorithmic bytes = {ratio}; "
                        + ("kernel source unchanged since that measurement" if fresh else
-                          f"STALE: csrc/mdr_mips.hip was {ent.get('csrc_sha16')} when measured, is {now} now -- re-run scripts/gpu_pmc_screen.sh") + ")")
+                          f"STALE: csrc/mdr_mips* was {ent.get('csrc_sha16')} when measured, is {now} now -- re-run scripts/gpu_pmc_screen.sh") + ")")
         hbm_bytes = alg_bytes * ratio
     else:
         hbm_bytes, src = float(args.pmc_traffic) * len(calls), "--pmc-traffic"

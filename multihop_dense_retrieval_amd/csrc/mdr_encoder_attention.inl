@@ -1,0 +1,373 @@
+// csrc/mdr_encoder_attention.inl -- attention kernels: one-shot (L <= 128), streaming (K / V chunks by LDS-DMA, transposing LDS reads), CLS-only last layer.
+// Included by mdr_encoder.hip inside namespace mdr::{anonymous}.
+// ---- attention: softmax(Q K^T / 8 + mask) V for one (sequence, head) ------------------------------------
+// K (XOR-swizzled rows) and V^T of the whole sequence are staged in LDS ONCE, then the 8 waves walk the
+// sequence's queries 128 at a time (16 per wave).
+template <int NT>  // key tiles of 16 the sequence may have (len <= 16*NT)
+__global__ void __launch_bounds__(512) attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
+                                                        _Float16* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int LP = NT * 16;
+    constexpr int VS = LP + 8;  // V^T row stride (halfs); +8 keeps 16-B alignment and staggers banks
+    _Float16* Ks = (_Float16*)lds;               // [LP][64], 128-B rows, 16-B slots XOR-swizzled by row&7
+    _Float16* Vt = (_Float16*)(lds + LP * 128);  // [64][VS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int start = cu[b], len = cu[b + 1] - start;
+    if (len <= 0) return;
+    const int nt = (len + 15) >> 4;
+    const int np = (nt + 1) >> 1;
+    const int H3 = 3 * H;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // staging: 4 (row, 16-byte chunk) items per thread per round, all 8 global loads issued before the LDS writes
+    const int items = np * 32 * 8;
+    for (int p0 = tid; p0 < items; p0 += 4 * 512) {
+        half8 kv[4], vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * 512, row = p >> 3, s = p & 7;
+            kv[u] = zero8;
+            vv[u] = zero8;
+            if (p < items && row < len) {
+                const _Float16* src = qkv + (size_t)(start + row) * H3 + h * 64 + s * 8;
+                kv[u] = *(const half8*)(src + H);
+                vv[u] = *(const half8*)(src + 2 * H);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * 512, row = p >> 3, s = p & 7;
+            if (p < items) {
+                *(half8*)((char*)Ks + row * 128 + ((s ^ (row & 7)) << 4)) = kv[u];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Vt[(s * 8 + j) * VS + row] = vv[u][j];
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int q0 = wave * 16; q0 < len; q0 += 128) {  // no barrier inside: the 8 waves run independently from here
+        const int qi = q0 + lr;
+        const bool qvalid = qi < len;
+        const int qrow = qvalid ? qi : len - 1;
+        half8 qf[2];
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const half8*)(qkv + (size_t)(start + qrow) * H3 + h * 64 + ds * 32 + g * 8);
+
+        // S^T tiles: lane holds keys 16t + 4g + r (r = 0..3) for query lr
+        f32x4 s[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (t < nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ds = 0; ds < 2; ++ds) {
+                    const half8 kf = *(const half8*)((const char*)Ks + (t * 16 + lr) * 128 + (((ds * 4 + g) ^ (lane & 7)) << 4));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ds], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * 16 + 4 * g + r;
+                    s[t][r] = key < len ? acc[r] * 0.125f : -INFINITY;
+                    mx = fmaxf(mx, s[t][r]);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f((s[t][r] - mx) * 1.4426950408889634f);  // argument <= 0: raw v_exp_f32
+                    s[t][r] = e;
+                    sum += e;
+                }
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.f / sum;
+
+        // O^T = V^T P^T. k-slot (g, j) of both operands <-> key 32pt + (j < 4 ? 4g + j : 16 + 4g + j - 4):
+        // the P operand is then exactly this lane's own S^T registers, no cross-lane traffic.
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pt = 0; pt < NT / 2; ++pt)
+            if (pt < np) {
+                half8 pf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pf[j] = (_Float16)(s[2 * pt][j] * inv);
+                    pf[4 + j] = (2 * pt + 1 < nt) ? (_Float16)(s[2 * pt + 1][j] * inv) : (_Float16)0.f;
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const _Float16* vp = Vt + (dt * 16 + lr) * VS + pt * 32 + 4 * g;
+                    const half4 lo = *(const half4*)vp;
+                    const half4 hi = *(const half4*)(vp + 16);
+                    const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+        if (qvalid) {
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));  // (see attention_stream_kernel's epilogue)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                half4 w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = (_Float16)o[dt][r];
+                *(half4*)(ctx + (size_t)(start + qi) * H + h * 64 + dt * 16 + 4 * g) = w;
+            }
+        }
+    }
+}
+
+
+// ---- attention, streaming form: one workgroup per (sequence, head, block of 128 queries) ---------------------
+// K and V of a key chunk (<= 16*NTC keys) are staged ROW-major by LDS-DMA (global_load_lds, 16-B slots XOR-swizzled by
+// key & 7 in the source address, rows past the sequence clamped to its last row so that every staged value is finite),
+// 32 KiB + 32 KiB at NTC = 16: two workgroups share a CU, so one stages while the other computes (the one-shot kernel
+// above needs 98 KiB and serialises its own staging and compute on a CU; its V^T staging writes are 8-way conflicted).
+// S^T = K Q^T on MFMA as above; the V^T operand of O^T = V^T P^T is read straight from the row-major image with
+// ds_read_b64_tr_b16 (lane a of a 16-lane group addresses row a >> 2, columns 4 (a & 3).. of a [4 keys][16 d] block and
+// receives column a: measured semantics, conflict-free with the key & 7 swizzle). Longer sequences take several chunks
+// with the usual running (max, sum) rescale; probabilities enter the PV product as fp16 of exp(s - max) <= 1 and the
+// 1 / sum is applied to the fp32 result.
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+#ifndef MDR_ATTN_MERGE
+#define MDR_ATTN_MERGE 1
+#endif
+#ifndef MDR_ATTN_FORCE
+#define MDR_ATTN_FORCE 0
+#endif
+// measurement builds (wrong results; scripts/gpu_attn_ab.sh): 1 no K fragment reads, 2 no V fragment reads, 3 neither, 4 staging only
+// (Q loads, K/V DMA, barrier, context stores), 5 no exp, 6 = 4 with K only, 7 = 4 without the stores, 8 = 4 with one row per DMA piece
+#ifndef MDR_ATTN_ABL
+#define MDR_ATTN_ABL 0
+#endif
+template <int NTC>  // key tiles of 16 per chunk
+__global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
+                                                               _Float16* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int KC = NTC * 16;
+    char* Ks = lds;              // [KC][64] halfs, 128-B rows
+    char* Vs = lds + KC * 128;   // same
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int start = cu[b], len = cu[b + 1] - start;
+    const int qb0 = blockIdx.z * 128;
+    if (qb0 >= len) return;
+    // A sequence whose keys fit ONE chunk (len <= KC) and that has two query blocks is served by its first workgroup alone: K and V
+    // are staged once and the second block of 128 queries runs over the same image (MDR_ATTN_MERGE=0 builds: one workgroup per block).
+    const bool merged = MDR_ATTN_MERGE && len <= KC && len > 128;
+    if (merged && blockIdx.z > 0) return;
+    const int nsub = merged ? 2 : 1;
+    const int H3 = 3 * H;
+
+    // DMA plan: wave-instruction i covers LDS slots 64 i .. 64 i + 63 = rows 8 i .. 8 i + 7; this lane: row 8 i + (lane >> 3),
+    // slot lane & 7 holding source chunk (lane & 7) ^ (row & 7) = (lane & 7) ^ (lane >> 3)
+    const int st_row = lane >> 3;
+    const int st_col = ((lane & 7) ^ st_row) * 8;
+    // reader offsets
+    const int k_rd = lr * 128;                       // + t * 2048 + (((ds * 4 + g) ^ (lr & 7)) << 4)
+    const int ksw0 = ((0 * 4 + g) ^ (lr & 7)) << 4, ksw1 = ((1 * 4 + g) ^ (lr & 7)) << 4;
+    const int vkey = 4 * g + (lr >> 2);              // key within a 16-key half of a pair-tile
+    const int vsw = vkey & 7;
+    int v_rd[4];                                     // byte offset of this lane's 8-B piece for d-tile dt, relative to the pair-tile row base
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) v_rd[dt] = vkey * 128 + ((((dt * 2 + ((lr & 3) >> 1)) ^ vsw)) << 4) + (lr & 1) * 8;
+
+    // The Q fragments of a query block are plain register loads; they are issued BEFORE the K/V DMA of the first chunk and retired by the
+    // same vmcnt(0) wait, so that Q, K and V travel together (one memory round trip instead of two: round 2 waited for Q first, and the
+    // staging chain -- cu[b], Q, K/V, barrier -- was 33 of the kernel's 47 us). The second query block of a merged pair is fetched into
+    // the same registers as soon as the first block's S tiles no longer need them, under that block's softmax and PV product.
+    half8 qf[2];
+    auto load_q = [&](int sub_) __attribute__((always_inline)) {
+        const int qi_ = qb0 + sub_ * 128 + wave * 16 + lr;
+        const int qrow_ = qi_ < len ? qi_ : len - 1;
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const half8*)(qkv + (size_t)(start + qrow_) * H3 + h * 64 + ds * 32 + g * 8);
+    };
+    load_q(0);
+    for (int sub = 0; sub < nsub; ++sub) {
+    const int q0 = qb0 + sub * 128 + wave * 16;
+    const bool wave_valid = q0 < len;  // waves past the sequence only help staging
+    const int qi = q0 + lr;
+    const bool qvalid = qi < len;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kc0 = 0; kc0 < len; kc0 += KC) {
+        const int ck = min(KC, len - kc0);     // keys of this chunk
+        const int nt = (ck + 15) >> 4;
+        const int np = (nt + 1) >> 1;
+        if (sub == 0) {                        // (the second block of a merged pair finds its single chunk staged)
+            if (kc0 > 0) __syncthreads();      // every wave is done reading the previous chunk
+            // ---- stage K and V rows kc0 .. kc0 + 32 np - 1 (clamped to len - 1)
+            for (int i = wave; i < np * 4; i += 8) {
+                int row = kc0 + i * 8 + (MDR_ATTN_ABL == 8 ? 0 : st_row);
+                row = row < len ? row : len - 1;
+                const _Float16* src = qkv + (size_t)(start + row) * H3 + H + h * 64 + st_col;
+                __builtin_amdgcn_global_load_lds(MDR_GPTR(src), MDR_LPTR(Ks + i * 1024), 16, 0, 0);
+                if (MDR_ATTN_ABL != 6) __builtin_amdgcn_global_load_lds(MDR_GPTR(src + H), MDR_LPTR(Vs + i * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K / V pieces AND (first chunk) the Q loads issued in front of them
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) asm volatile("" : "+v"(qf[ds]));
+            __syncthreads();
+        }
+        if (MDR_ATTN_ABL == 4 || MDR_ATTN_ABL >= 6) continue;
+        if (!wave_valid) continue;
+
+        // ---- S^T tiles of this chunk: lane holds keys kc0 + 16 t + 4 g + r for query lr
+        f32x4 s[NTC];
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) {
+            s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (t < nt) {
+                half8 k0, k1;
+                if (MDR_ATTN_ABL == 1 || MDR_ATTN_ABL == 3) { k0 = qf[1]; k1 = qf[0]; }
+                else {
+                    k0 = *(const half8*)(Ks + k_rd + t * 2048 + ksw0);
+                    k1 = *(const half8*)(Ks + k_rd + t * 2048 + ksw1);
+                }
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], acc, 0, 0, 0);
+                acc *= 0.125f;
+                if (t == nt - 1) {  // only the chunk's last tile can hold keys past the sequence (clamped copies of its last row)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kc0 + t * 16 + 4 * g + r >= len) acc[r] = -INFINITY;
+                }
+                s[t] = acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, acc[r]);
+            }
+        }
+        if (merged && sub == 0) load_q(1);  // (merged: one chunk) the next block's Q, under this block's softmax and PV product
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+        const float m_new = fmaxf(m_run, cmax);  // finite: every chunk holds at least one valid key
+        const float alpha = exp2f((m_run - m_new) * 1.4426950408889634f);  // 0 on the first chunk
+        const float mb = -m_new * 1.4426950408889634f;
+        float csum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NTC; ++t)
+            if (t < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = MDR_ATTN_ABL == 5 ? fmaf(s[t][r], 1.4426950408889634f, mb)
+                                                      : __builtin_amdgcn_exp2f(fmaf(s[t][r], 1.4426950408889634f, mb));  // argument <= 0 (up to rounding): raw v_exp_f32
+                    s[t][r] = e;
+                    csum += e;
+                }
+            }
+        csum += __shfl_xor(csum, 16);
+        csum += __shfl_xor(csum, 32);
+        l_run = l_run * alpha + csum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+
+        // ---- O^T += V^T P^T. k-slot (g, j) of both operands <-> key 32 pt + (j < 4 ? 4g + j : 16 + 4g + j - 4): the P operand
+        // is this lane's own S^T registers, the V^T operand two transposing reads of the row-major V image
+#pragma unroll
+        for (int pt = 0; pt < NTC / 2; ++pt)
+            if (pt < np) {
+                half8 pf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pf[j] = (_Float16)s[2 * pt][j];
+                    pf[4 + j] = (2 * pt + 1 < nt) ? (_Float16)s[2 * pt + 1][j] : (_Float16)0.f;
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    if (MDR_ATTN_ABL == 2 || MDR_ATTN_ABL == 3) { o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[dt & 1], pf, o[dt], 0, 0, 0); continue; }
+                    const char* vp = Vs + pt * 4096 + v_rd[dt];
+                    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)vp);
+                    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vp + 2048));
+                    const half8 vf = {(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3],
+                                      (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+    }
+    if (qvalid && MDR_ATTN_ABL != 7) {
+        // The last PV MFMAs sit behind per-pair branches, and hipcc's hazard recogniser does not look across a branch for the
+        // distance a VALU read of an MFMA result needs (found with a variant of this kernel that consumed S tiles right behind a
+        // per-tile branch: NaNs, gone with the nops). Nothing has ever been wrong here; the 16 wait states are insurance.
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+        const float inv = 1.f / l_run;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            half4 w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = (_Float16)(o[dt][r] * inv);
+            *(half4*)(ctx + (size_t)(start + qi) * H + h * 64 + dt * 16 + 4 * g) = w;
+        }
+    }
+    }  // sub
+}
+
+// Last layer: only the CLS row of each sequence feeds the projection head, so its attention needs ONE query per
+// (sequence, head). One wave per (sequence, head): scores over the keys (lane = key), softmax, then lane = feature.
+__global__ void __launch_bounds__(64) attention_cls_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
+                                                           _Float16* __restrict__ ctx_cls /* [B, H] */) {
+    __shared__ float p_s[512];
+    __shared__ float q_s[64];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int start = cu[b], len = cu[b + 1] - start;
+    if (len <= 0) return;
+    const int H3 = 3 * H;
+    q_s[lane] = (float)qkv[(size_t)start * H3 + h * 64 + lane] * 0.125f;
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int key = lane; key < len; key += 64) {
+        const _Float16* kp = qkv + (size_t)(start + key) * H3 + H + h * 64;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const half8 kv = *(const half8*)(kp + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = fmaf((float)kv[j], q_s[c * 8 + j], s);
+        }
+        p_s[key] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int key = lane; key < len; key += 64) {
+        const float e = exp2f((p_s[key] - mx) * 1.4426950408889634f);
+        p_s[key] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const float inv = 1.f / sum;
+    float o = 0.f;
+    for (int key = 0; key < len; ++key)  // P rounded to fp16 like the MFMA path (apex O1: probs enter the PV matmul as fp16)
+        o = fmaf((float)(_Float16)(p_s[key] * inv), (float)qkv[(size_t)(start + key) * H3 + 2 * H + h * 64 + lane], o);
+    ctx_cls[(size_t)b * H + h * 64 + lane] = (_Float16)o;
+}
+
+template <int NT>
+constexpr int attention_lds_bytes() { return NT * 16 * 128 + 64 * (NT * 16 + 8) * 2; }

@@ -41,7 +41,9 @@ for f in sorted(glob.glob(sys.argv[1] + "/*_*.csv")):
 def mean(v): return sum(v) / len(v) if v else 0.0
 repo = sys.argv[2]
 alg = 5_000_000 * 768 * 4.0
-sha = hashlib.sha256(open(os.path.join(repo, "multihop_dense_retrieval_amd", "csrc", "mdr_mips.hip"), "rb").read()).hexdigest()[:16]
+sys.path.insert(0, repo)
+import bench
+sha = bench.src_sha16()  # over csrc/mdr_mips* (the same function bench.py checks freshness with)
 path = os.path.join(repo, "profiles", "pmc_traffic.json")
 try: tbl = json.load(open(path))
 except Exception: tbl = {"kernels": {}}
