@@ -163,7 +163,8 @@ int launch_add(mdr_index* h, const T* src_dev, long long n, long long row0, hipS
             hipLaunchKernelGGL(centre_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)sums, h->d, 1.0f / (float)nc, h->centre);
             h->centre_set = true;
         }
-        hipLaunchKernelGGL(convert_to_i8_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src_dev, n, h->d, row0, h->i8, h->flags + 8,
+        const long long want = (n + 3) / 4, cap = (long long)h->num_cus * 32;  // a wave walks rows r, r + 4 * grid, ...: centre and weights stay in registers
+        hipLaunchKernelGGL(convert_to_i8_kernel<T>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, src_dev, n, h->d, row0, h->i8, h->flags + 8,
                            (const float*)h->centre);
     }
     MDR_HIP_TRY(hipGetLastError());

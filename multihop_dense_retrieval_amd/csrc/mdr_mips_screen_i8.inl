@@ -140,46 +140,54 @@ template <typename T>
 __global__ void __launch_bounds__(256) convert_to_i8_kernel(const T* __restrict__ src, long long n, int d, long long row0, char* __restrict__ dst,
                                                             int* __restrict__ stats, const float* __restrict__ centre) {
     const int lane = threadIdx.x & 63;
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n) return;
     const int nkb8 = d >> 6;
     const bool on = lane < (d >> 4);
-    float x[16];
-    float mx = 0.f;
+    float cj[16], iw[16];  // this lane's 16 columns of the centre and of 1 / w: loaded once, the wave then walks its rows
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        x[j] = on ? (load_as_f32<T>(src + r * (long long)d + lane * 16 + j) - centre[lane * 16 + j]) * centre[d + lane * 16 + j] : 0.f;  // (x - c) / w
-        mx = fmaxf(mx, fabsf(x[j]));
+        cj[j] = on ? centre[lane * 16 + j] : 0.f;
+        iw[j] = on ? centre[d + lane * 16 + j] : 0.f;
     }
-    mx = wave_max_f(mx);
-    const float sc = mx > 0.f ? mx / 127.f : 0.f;
-    const float inv = mx > 0.f ? 127.f / mx : 0.f;
-    int l1 = 0;
-    i32x4 packed;
+    float smax = 0.f, cmax = 0.f;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (long long)gridDim.x * 4) {
+        float x[16];
+        float mx = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        unsigned u = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            int v = (int)rintf(x[4 * w + b] * inv);
-            v = v > 127 ? 127 : (v < -127 ? -127 : v);
-            l1 += v < 0 ? -v : v;
-            u |= ((unsigned)v & 0xFFu) << (8 * b);
+        for (int j = 0; j < 16; ++j) {
+            x[j] = on ? (load_as_f32<T>(src + r * (long long)d + lane * 16 + j) - cj[j]) * iw[j] : 0.f;  // (x - c) / w
+            mx = fmaxf(mx, fabsf(x[j]));
         }
-        packed[w] = (int)u;
+        mx = wave_max_f(mx);
+        const float sc = mx > 0.f ? mx / 127.f : 0.f;
+        const float inv = mx > 0.f ? 127.f / mx : 0.f;
+        int l1 = 0;
+        i32x4 packed;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned u = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                int v = (int)rintf(x[4 * w + b] * inv);
+                v = v > 127 ? 127 : (v < -127 ? -127 : v);
+                l1 += v < 0 ? -v : v;
+                u |= ((unsigned)v & 0xFFu) << (8 * b);
+            }
+            packed[w] = (int)u;
+        }
+        l1 = wave_sum_i(l1);
+        const long long row = row0 + r;
+        char* sb = dst + (size_t)(row >> 5) * i8_sb_bytes(nkb8);
+        if (on) {
+            const int kb = lane >> 2, g = lane & 3;
+            *(i32x4*)(sb + ((size_t)((row >> 4) & 1) * nkb8 + kb) * kFragBytes + (g * 16 + (int)(row & 15)) * 16) = packed;
+        }
+        if (lane == 0) *(float*)(sb + (size_t)2 * nkb8 * kFragBytes + (row & 31) * 4) = sc;
+        smax = fmaxf(smax, sc);
+        cmax = fmaxf(cmax, sc * (0.5f * (float)l1 + 0.25f * (float)d));
     }
-    l1 = wave_sum_i(l1);
-    const long long row = row0 + r;
-    char* sb = dst + (size_t)(row >> 5) * i8_sb_bytes(nkb8);
-    if (on) {
-        const int kb = lane >> 2, g = lane & 3;
-        *(i32x4*)(sb + ((size_t)((row >> 4) & 1) * nkb8 + kb) * kFragBytes + (g * 16 + (int)(row & 15)) * 16) = packed;
-    }
-    if (lane == 0) {
-        *(float*)(sb + (size_t)2 * nkb8 * kFragBytes + (row & 31) * 4) = sc;
-        const float c = sc * (0.5f * (float)l1 + 0.25f * (float)d);
-        if (__float_as_int(sc) > stats[0]) atomicMax(stats + 0, __float_as_int(sc));
-        if (__float_as_int(c) > stats[1]) atomicMax(stats + 1, __float_as_int(c));
+    if (lane == 0) {  // one pair of atomics per wave instead of per row
+        if (__float_as_int(smax) > stats[0]) atomicMax(stats + 0, __float_as_int(smax));
+        if (__float_as_int(cmax) > stats[1]) atomicMax(stats + 1, __float_as_int(cmax));
     }
 }
 
