@@ -9,7 +9,9 @@ TAG=${1:-pmcs}; REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TM
 cd /tmp
 for MODE in sequential pipelined; do
   FLAG=""; [ $MODE = sequential ] && FLAG="--sequential"
-  for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
+  SETS=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIVE")
+  [ "${PMC_FETCH_ONLY:-0}" = 1 ] && SETS=("FETCH_SIZE")   # the pass profiles/pmc_traffic.json is made from
+  for PMC in "${SETS[@]}"; do
     N=$(echo $PMC | tr ' ' '_' | cut -c1-30)
     timeout 300 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/p -o p -- python $REPO/bench.py --rows 5000000 --steps 3 --warmup 1 --no-encoder --no-cpu-baseline --no-sequential --no-verify $FLAG > $OUT/log_${MODE}_$N.txt 2>&1
     P=$(find $OUT/p -name "*counter_collection.csv" | head -1)
