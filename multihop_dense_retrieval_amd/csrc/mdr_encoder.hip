@@ -38,6 +38,7 @@ namespace {
 
 #include "mdr_encoder_pack_ln.inl"
 #include "mdr_encoder_gemm.inl"
+#include "mdr_encoder_gemm_quad.inl"
 #include "mdr_encoder_attention.inl"
 
 }  // namespace
@@ -137,6 +138,17 @@ int launch_gemm_big(const _Float16* A, int lda, const _Float16* W, const float* 
     return MDR_OK;
 }
 
+template <int EPI>
+int launch_gemm_quad(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
+                     int M_est, int num_cus, hipStream_t st) {
+    constexpr int lds = GemmB2::LDS_BYTES + kPersistBiasMax * 4 + 4 * 4096;  // slots + bias + per-wave epilogue scratch
+    const int grid = num_cus / 8 * 8;
+    { int rc_ = ensure_dynamic_lds((const void*)gemm_quad_kernel<EPI>, lds); if (rc_) return rc_; }
+    hipLaunchKernelGGL((gemm_quad_kernel<EPI>), dim3(grid), dim3(256), lds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
 // M_est: expected number of valid rows (the packed token count is only known on the device).
 // *res_added tells the caller whether the residual went into the output (else the following LayerNorm adds it).
 template <int EPI>
@@ -145,15 +157,16 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
     // experiment knob: 1 small, 2 mid, 3 big tiles; 4 persistent 256x128 / 6 persistent 256x256 for the large-M calls (the others keep the heuristic)
     static int env_sel = getenv("MDR_GEMM_CFG") ? atoi(getenv("MDR_GEMM_CFG")) : 0;
     int sel = force >= 0 ? force : env_sel;
-    if (force < 0 && (sel == 4 || sel == 6) && (long long)(N / 128) * ((M_est + 255) / 256) < (long long)num_cus * 3 / 2) sel = 0;
+    if (force < 0 && (sel == 4 || sel == 6 || sel == 7) && (long long)(N / 128) * ((M_est + 255) / 256) < (long long)num_cus * 3 / 2) sel = 0;
     if (res_added) *res_added = true;
     const long long p_tiles = (long long)(N / 128) * ((M_est + 255) / 256);
-    if ((sel == 4 || sel == 6 || (sel == 0 && p_tiles >= (long long)num_cus * 3 / 2)) && N % 128 == 0 && N <= kPersistBiasMax) {
+    if ((sel == 4 || sel == 6 || sel == 7 || (sel == 0 && p_tiles >= (long long)num_cus * 3 / 2)) && N % 128 == 0 && N <= kPersistBiasMax) {
         if (res_added) *res_added = false;
         else if (EPI == EPI_BIAS_RES_F32) return set_error(MDR_E_STATE, "large-M GEMM with a residual needs the caller to take the residual (res_added)");
         constexpr int E = EPI == EPI_BIAS_RES_F32 ? EPI_BIAS_F32 : EPI;
         // Both kernels are bound by the bytes a CU moves over its L2 path, loads AND stores (~20 B/clk/CU measured; skipping
         // the stores made the K = 768 GEMMs 25-30 % faster, deferring them did not): cost = rounds x (tile inputs + outputs).
+        if (sel == 7 && N % 256 == 0) return launch_gemm_quad<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
         if ((sel == 6 || sel == 0) && N % 256 == 0) {
             const double osz = (E == EPI_BIAS_F32) ? 4.0 : 2.0;
             const double c_big = persistent_rounds(M_est, 256, N, 256, num_cus / 8) * ((256.0 + 256.0) * K * 2 + 256.0 * 256.0 * osz);
@@ -325,9 +338,9 @@ int mdr_test_gemm_f16(const void* A_dev, const void* W_dev, const float* bias_de
     MDR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "bad GEMM shape M=%d N=%d K=%d (N, K multiples of 64)", M, N, K);
     MDR_REQUIRE(epilogue == EPI_BIAS_F16 || epilogue == EPI_BIAS_GELU_F16 || epilogue == EPI_BIAS_F32, "epilogue must be 0, 1 or 3");
 #ifdef MDR_GEMM_EXTRA_CFGS
-    MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 6 || (kernel >= 8 && kernel <= 13), "kernel must be 0, 1, 2, 4, 6 or 8-13");
+    MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 6 || kernel == 7 || (kernel >= 8 && kernel <= 13), "kernel must be 0, 1, 2, 4, 6, 7 or 8-13");
 #else
-    MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 6, "kernel must be 0, 1, 2, 4 or 6");
+    MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 6 || kernel == 7, "kernel must be 0, 1, 2, 4, 6 or 7");
 #endif
     DeviceGuard guard(device);
     if (!guard.ok) return set_error(MDR_E_HIP, "hipSetDevice(%d) failed", device);

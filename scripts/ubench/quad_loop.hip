@@ -1,0 +1,69 @@
+// Micro-benchmark: the K-loop of a 256x256x64 f16 GEMM tile on FOUR waves of 128x128 (one per SIMD, 512 registers each), written as one
+// hand-scheduled asm block (scripts/ubench/gen_quad_loop.py -> quad_loop.inc): can a single wave per SIMD keep the matrix pipe fed while it
+// also issues the fragment reads, the LDS-DMA pieces and one barrier per K-tile?  No epilogue, results unused; operands random (clocks).
+// Same operand sharing between the workgroups of an XCD as gemm_big_kernel's FFN2 walk (A panel by 3 workgroups, 3 W panels).
+// Build: python gen_quad_loop.py > quad_loop.inc && hipcc --offload-arch=gfx950 -O3 quad_loop.hip -o quad_loop
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+quad_loop(const char* __restrict__ A, const char* __restrict__ W, int row_stride, int ktiles, unsigned long long* __restrict__ cyc, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, g = lane >> 4, lr = lane & 15;
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+    const char* a_panel = A + (size_t)(xcd * 11 + lb / 3) * 256 * row_stride;
+    const char* w_panel = W + (size_t)(lb % 3) * 256 * row_stride;
+    const int ld_row = tid >> 3;
+    const unsigned off0 = (unsigned)ld_row * row_stride + (((tid & 7) ^ (ld_row & 7)) * 16);
+    const unsigned rs32 = 32u * row_stride;
+    const unsigned lds0 = (unsigned)(size_t)lds;  // 0: dynamic LDS starts at 0
+    const unsigned rda = lds0 + (wr * 128 + lr) * 128 + ((g ^ (lane & 7)) << 4);
+    const unsigned rdw = lds0 + 32768 + (wc * 128 + lr) * 128 + ((g ^ (lane & 7)) << 4);
+    const unsigned dst0 = lds0 + wave * 1024;
+    float o0, o1;
+    unsigned t0, t1;
+    const unsigned sw = 64;
+    asm volatile(
+#include "quad_loop.inc"
+        : [o0] "=v"(o0), [o1] "=v"(o1), [t0] "=v"(t0), [t1] "=v"(t1)
+        : [A] "s"(a_panel), [W] "s"(w_panel), [kt] "s"(ktiles), [rda] "v"(rda), [rdw] "v"(rdw), [sw] "v"(sw), [off0] "v"(off0), [rs32] "s"(rs32), [dst0] "s"(dst0)
+        : "memory", "m0", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29",
+#include "quad_loop_clobbers.inc"
+    );
+    if (tid == 0) atomicAdd(cyc, ((unsigned long long)t1 << 32) | t0);
+    if (o0 + o1 == 123.456f) sink[blockIdx.x] = o0;
+}
+
+int main(int argc, char** argv) {
+    const int row_stride = argc > 1 ? atoi(argv[1]) : 6144;
+    const int ktiles = row_stride / 128;
+    const size_t a_bytes = (size_t)8 * 11 * 256 * row_stride + (1 << 20), w_bytes = (size_t)3 * 256 * row_stride + (1 << 20);
+    std::vector<_Float16> h((a_bytes + w_bytes) / 2);
+    srand(1);
+    for (auto& v : h) v = (_Float16)((rand() / (float)RAND_MAX - 0.5f) * 2.f);
+    char *A, *W; unsigned long long* cyc; float* sink;
+    hipMalloc(&A, a_bytes); hipMalloc(&W, w_bytes); hipMalloc(&cyc, 8); hipMalloc(&sink, 4096);
+    hipMemcpy(A, h.data(), a_bytes, hipMemcpyHostToDevice);
+    hipMemcpy(W, (char*)h.data() + a_bytes, w_bytes, hipMemcpyHostToDevice);
+    const int lds_bytes = 160 * 1024 - 4096;
+    hipFuncSetAttribute((const void*)quad_loop, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemset(cyc, 0, 8);
+        hipEventRecord(e0);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(quad_loop, dim3(240), dim3(256), lds_bytes, 0, A, W, row_stride, ktiles, cyc, sink);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+        const double per_kt = (double)c / (240.0 * 10 * ktiles);
+        printf("row stride %d, %d K-tiles per workgroup, 240 workgroups: %.1f us per launch, %.0f clk per K-tile (s_memtime, wave 0), %.2f PFLOP/s on the K-loop alone\n",
+               row_stride, ktiles, ms / 10 * 1e3, per_kt, 240.0 * ktiles * 256 * 256 * 64 * 2 / (ms / 10 * 1e-3) / 1e15);
+    }
+    return 0;
+}
