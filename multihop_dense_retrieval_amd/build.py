@@ -24,7 +24,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inl")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inl")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(INCLUDE, "*.h"))
     return any(os.path.getmtime(p) > t for p in deps)
 
 
