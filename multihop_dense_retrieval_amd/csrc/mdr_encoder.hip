@@ -171,7 +171,15 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
             const double osz = (E == EPI_BIAS_F32) ? 4.0 : 2.0;
             const double c_big = persistent_rounds(M_est, 256, N, 256, num_cus / 8) * ((256.0 + 256.0) * K * 2 + 256.0 * 256.0 * osz);
             const double c_p = persistent_rounds(M_est, 256, N, 128, num_cus / 8) * ((256.0 + 128.0) * K * 2 + 256.0 * 128.0 * osz);
-            if (sel == 6 || c_big < c_p) return launch_gemm_big<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
+            if (sel == 6 || c_big < c_p) {
+                // four waves of 128x128 (gemm_quad_kernel): a faster K-loop (fewer LDS reads, one barrier per K-tile) behind a slower epilogue (one
+                // wave per SIMD has nobody to hide its latencies). Measured at 20.3 k rows: FFN2 77 vs 83-86 us, out-projection 30-33 vs 31-37,
+                // but QKV 84-89 vs 70-72 and FFN1 113-123 vs 106-117 (three / four tiles per workgroup, K = 768): taken where the K-loop dominates.
+                const int rounds = persistent_rounds(M_est, 256, N, 256, num_cus / 8);
+                if (sel == 0 && K % 128 == 0 && K >= 256 && (rounds == 1 || K >= 2048))
+                    return launch_gemm_quad<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
+                return launch_gemm_big<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
+            }
         }
         return launch_gemm_persist<E, GemmP>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
     }

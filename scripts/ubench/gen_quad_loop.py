@@ -18,26 +18,32 @@ import argparse
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--sched", default="3,3,3,3,2,2,0,0", help="DMA pieces per sub-phase (16 MFMAs): 4 of phase 1, then 4 of the next phase 0")
+ap.add_argument("--nf", type=int, default=8, help="n-fragments per wave: 8 = 128x128 wave tile (256x256 workgroup tile), 4 = 128x64 (256x128)")
+ap.add_argument("--stores", type=int, default=0, help="global_store_dwordx4 per K-tile and wave behind the barrier (epilogue traffic of an overlapped design)")
 ap.add_argument("--no-mfma", action="store_true")
 ap.add_argument("--no-reads", action="store_true")
 ap.add_argument("--no-dma", action="store_true")
 ap.add_argument("--no-barrier", action="store_true")
 args = ap.parse_args()
 sched = [int(x) for x in args.sched.split(",")]
-assert len(sched) == 8 and sum(sched) == 16
-k_first = sum(sched[:4])
+NF = args.nf
+SUBS = NF // 4 * 2          # 16-MFMA sub-phases per phase
+NPIECE = 8 + NF             # DMA pieces per wave and K-tile (A: 8 x 32 rows, W: NF x 32 rows)
+assert len(sched) == 2 * SUBS and sum(sched) == NPIECE and max(sched) <= 4
+k_first = sum(sched[:SUBS])
+A0, W0, A1, W1 = 0, 32, 32 + 4 * NF, 64 + 4 * NF   # fragment register bases
 
 out = []
 emit = out.append
 
 
 def acc(m, n):
-    b = 4 * (8 * m + n)
+    b = 4 * (NF * m + n)
     return f"a[{b}:{b + 3}]"
 
 
 def frag(buf, kind, i):  # kind 0 = A, 1 = W
-    b = 64 * buf + 32 * kind + 4 * i
+    b = (A0, W0, A1, W1)[2 * buf + kind] + 4 * i
     return f"v[{b}:{b + 3}]"
 
 
@@ -52,26 +58,29 @@ def phase(h):
     hn = h ^ 1
     rdA, rdW = (128, 129) if hn == 0 else (130, 131)
     reads = []
-    for i in range(8):  # W first (used by every MFMA row), then A
+    for i in range(NF):  # W first (used by every MFMA row), then A
         reads.append(f"ds_read_b128 {frag(hn, 1, i)}, v{rdW} offset:{i * 2048}")
     for i in range(8):
         reads.append(f"ds_read_b128 {frag(hn, 0, i)}, v{rdA} offset:{i * 2048}")
     if args.no_reads:
         reads = []
-    pcs = sched[0:4] if h == 1 else sched[4:8]
+    pcs = sched[0:SUBS] if h == 1 else sched[SUBS:2 * SUBS]
     base = 0 if h == 1 else k_first
-    # slots: index 0..63 behind MFMA i
-    slots = [[] for _ in range(64)]
+    # slots: index 0..16*SUBS-1 behind MFMA i
+    slots = [[] for _ in range(16 * SUBS)]
     for i, r in enumerate(reads):
         slots[i].append(r)
     c = base
-    for j in range(4):
+    for j in range(SUBS):
         for p in range(pcs[j]):
-            slots[16 * j + 9 + 2 * p if pcs[j] <= 4 else 16 * j + 4 + p].extend(piece(c))
+            slots[16 * j + 9 + 2 * p].extend(piece(c))
             c += 1
+    if h == 1:
+        for p in range(args.stores):
+            slots[2 + 3 * p].append(f"global_store_dwordx4 v148, v[152:155], s[30:31] offset:{256 * p}")
     k = 0
-    for j in range(4):
-        mg, ng = j >> 1, j & 1
+    for j in range(SUBS):
+        mg, ng = (j >> 1, j & 1) if NF == 8 else (j, 0)
         for i in range(16):
             q, n = i >> 2, i & 3
             m_, n_ = 4 * mg + q, 4 * ng + n
@@ -96,12 +105,14 @@ emit("v_mov_b32 v132, %[off0]")
 for c in range(1, 8):
     emit(f"v_add_u32 v{132 + c}, %[rs32], v{131 + c}")
 emit("v_mov_b32 v140, %[off0]")
-for c in range(9, 16):
+for c in range(9, NPIECE):
     emit(f"v_add_u32 v{132 + c}, %[rs32], v{131 + c}")
+emit("s_mov_b64 s[30:31], %[st]")
+emit("v_mov_b32 v148, %[stoff]")
 for i in range(256):
     emit(f"v_accvgpr_write_b32 a{i}, 0")
 emit("s_memtime s[26:27]")
-for c in range(16):
+for c in range(NPIECE):
     for s in piece(c):
         emit(s)
 emit("s_add_u32 s20, s20, 128")
@@ -116,7 +127,7 @@ emit(f"s_waitcnt vmcnt({0 if args.no_dma else k_first})")
 if not args.no_barrier:
     emit("s_barrier")
 if not args.no_reads:
-    for i in range(8):
+    for i in range(NF):
         emit(f"ds_read_b128 {frag(0, 1, i)}, v129 offset:{i * 2048}")
     for i in range(8):
         emit(f"ds_read_b128 {frag(0, 0, i)}, v128 offset:{i * 2048}")
@@ -137,6 +148,9 @@ emit("v_xor_b32 v129, 0x10000, v129")
 phase(1)
 emit("v_xor_b32 v130, 0x10000, v130")
 emit("v_xor_b32 v131, 0x10000, v131")
+if args.stores:
+    emit("s_add_u32 s30, s30, 0x10000")
+    emit("s_addc_u32 s31, s31, 0")
 emit("s_sub_u32 s24, s24, 1")
 emit("s_cmp_lg_u32 s24, 0")
 emit("s_cbranch_scc1 1b")
@@ -145,7 +159,7 @@ emit("s_nop 15")
 emit("s_nop 15")
 emit("s_memtime s[28:29]")
 emit("v_accvgpr_read_b32 %[o0], a0")
-emit("v_accvgpr_read_b32 %[o1], a255")
+emit(f"v_accvgpr_read_b32 %[o1], a{32 * NF - 1}")
 emit("s_waitcnt lgkmcnt(0)")
 emit("s_sub_u32 s26, s28, s26")
 emit("s_subb_u32 s27, s29, s27")

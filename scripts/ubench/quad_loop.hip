@@ -7,9 +7,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#ifndef QUAD_NF
+#define QUAD_NF 8
+#endif
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-quad_loop(const char* __restrict__ A, const char* __restrict__ W, int row_stride, int ktiles, unsigned long long* __restrict__ cyc, float* __restrict__ sink) {
+quad_loop(const char* __restrict__ A, const char* __restrict__ W, int row_stride, int ktiles, unsigned long long* __restrict__ cyc, float* __restrict__ sink, char* __restrict__ st) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -22,7 +25,9 @@ quad_loop(const char* __restrict__ A, const char* __restrict__ W, int row_stride
     const unsigned rs32 = 32u * row_stride;
     const unsigned lds0 = (unsigned)(size_t)lds;  // 0: dynamic LDS starts at 0
     const unsigned rda = lds0 + (wr * 128 + lr) * 128 + ((g ^ (lane & 7)) << 4);
-    const unsigned rdw = lds0 + 32768 + (wc * 128 + lr) * 128 + ((g ^ (lane & 7)) << 4);
+    const unsigned rdw = lds0 + 32768 + (wc * (16 * QUAD_NF) + lr) * 128 + ((g ^ (lane & 7)) << 4);
+    const char* stp = st + (size_t)blockIdx.x * (4u << 20);  // 4 MiB of store space per workgroup, walked 64 KiB per K-tile
+    const unsigned stoff = tid * 16;
     const unsigned dst0 = lds0 + wave * 1024;
     float o0, o1;
     unsigned t0, t1;
@@ -30,8 +35,8 @@ quad_loop(const char* __restrict__ A, const char* __restrict__ W, int row_stride
     asm volatile(
 #include "quad_loop.inc"
         : [o0] "=v"(o0), [o1] "=v"(o1), [t0] "=v"(t0), [t1] "=v"(t1)
-        : [A] "s"(a_panel), [W] "s"(w_panel), [kt] "s"(ktiles), [rda] "v"(rda), [rdw] "v"(rdw), [sw] "v"(sw), [off0] "v"(off0), [rs32] "s"(rs32), [dst0] "s"(dst0)
-        : "memory", "m0", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29",
+        : [A] "s"(a_panel), [W] "s"(w_panel), [kt] "s"(ktiles), [rda] "v"(rda), [rdw] "v"(rdw), [sw] "v"(sw), [off0] "v"(off0), [rs32] "s"(rs32), [dst0] "s"(dst0), [st] "s"(stp), [stoff] "v"(stoff)
+        : "memory", "m0", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "v148", "v152", "v153", "v154", "v155",
 #include "quad_loop_clobbers.inc"
     );
     if (tid == 0) atomicAdd(cyc, ((unsigned long long)t1 << 32) | t0);
@@ -45,7 +50,8 @@ int main(int argc, char** argv) {
     std::vector<_Float16> h((a_bytes + w_bytes) / 2);
     srand(1);
     for (auto& v : h) v = (_Float16)((rand() / (float)RAND_MAX - 0.5f) * 2.f);
-    char *A, *W; unsigned long long* cyc; float* sink;
+    char *A, *W, *st; unsigned long long* cyc; float* sink;
+    hipMalloc(&st, (size_t)1 << 30);
     hipMalloc(&A, a_bytes); hipMalloc(&W, w_bytes); hipMalloc(&cyc, 8); hipMalloc(&sink, 4096);
     hipMemcpy(A, h.data(), a_bytes, hipMemcpyHostToDevice);
     hipMemcpy(W, (char*)h.data() + a_bytes, w_bytes, hipMemcpyHostToDevice);
@@ -56,14 +62,14 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 3; ++rep) {
         hipMemset(cyc, 0, 8);
         hipEventRecord(e0);
-        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(quad_loop, dim3(240), dim3(256), lds_bytes, 0, A, W, row_stride, ktiles, cyc, sink);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(quad_loop, dim3(240), dim3(256), lds_bytes, 0, A, W, row_stride, ktiles, cyc, sink, st);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
         const double per_kt = (double)c / (240.0 * 10 * ktiles);
         printf("row stride %d, %d K-tiles per workgroup, 240 workgroups: %.1f us per launch, %.0f clk per K-tile (s_memtime, wave 0), %.2f PFLOP/s on the K-loop alone\n",
-               row_stride, ktiles, ms / 10 * 1e3, per_kt, 240.0 * ktiles * 256 * 256 * 64 * 2 / (ms / 10 * 1e-3) / 1e15);
+               row_stride, ktiles, ms / 10 * 1e3, per_kt, 240.0 * ktiles * 256 * (32.0 * QUAD_NF) * 64 * 2 / (ms / 10 * 1e-3) / 1e15);
     }
     return 0;
 }
