@@ -39,7 +39,6 @@ namespace {
 #include "mdr_encoder_pack_ln.inl"
 #include "mdr_encoder_gemm.inl"
 #include "mdr_encoder_gemm_quad.inl"
-#include "mdr_encoder_gemm_duo.inl"
 #include "mdr_encoder_attention.inl"
 
 }  // namespace
@@ -150,30 +149,6 @@ int launch_gemm_quad(const _Float16* A, int lda, const _Float16* W, const float*
     return MDR_OK;
 }
 
-// gemm_duo_kernel serves K = 768 (12 K-tiles) with either output type and K >= 1152, K % 192 == 0 with fp32 output (FFN2); no GELU epilogue yet
-template <int EPI>
-constexpr bool duo_has(int K) {
-    return (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_F32) && (K == 768 || (EPI == EPI_BIAS_F32 && K >= 1152 && K % 192 == 0));
-}
-template <int EPI>
-int launch_gemm_duo(const _Float16* A, int lda, const _Float16* W, const float* bias, int M_cap, const int* M_dev, int N, int K, void* out, int ldo,
-                    int M_est, int num_cus, hipStream_t st) {
-    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_F32) {
-        const int grid = num_cus / 8 * 8;
-        if (K == 768) {
-            { int rc_ = ensure_dynamic_lds((const void*)gemm_duo_kernel<EPI, false>, kDuoLds); if (rc_) return rc_; }
-            hipLaunchKernelGGL((gemm_duo_kernel<EPI, false>), dim3(grid), dim3(256), kDuoLds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo);
-        } else if constexpr (EPI == EPI_BIAS_F32) {
-            { int rc_ = ensure_dynamic_lds((const void*)gemm_duo_kernel<EPI, true>, kDuoLds); if (rc_) return rc_; }
-            hipLaunchKernelGGL((gemm_duo_kernel<EPI, true>), dim3(grid), dim3(256), kDuoLds, st, A, lda, W, bias, M_cap, M_dev, N, K, out, ldo);
-        }
-        MDR_HIP_TRY(hipGetLastError());
-        return MDR_OK;
-    } else {
-        return set_error(MDR_E_STATE, "gemm_duo_kernel has no GELU epilogue");
-    }
-}
-
 // M_est: expected number of valid rows (the packed token count is only known on the device).
 // *res_added tells the caller whether the residual went into the output (else the following LayerNorm adds it).
 template <int EPI>
@@ -182,21 +157,15 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
     // experiment knob: 1 small, 2 mid, 3 big tiles; 4 persistent 256x128 / 6 persistent 256x256 for the large-M calls (the others keep the heuristic)
     static int env_sel = getenv("MDR_GEMM_CFG") ? atoi(getenv("MDR_GEMM_CFG")) : 0;
     int sel = force >= 0 ? force : env_sel;
-    const bool no_duo = sel == 60;  // MDR_GEMM_CFG=60: the heuristic without gemm_duo_kernel (A/B runs)
-    if (no_duo) sel = 0;
-    if (force < 0 && (sel == 4 || sel == 5 || sel == 6 || sel == 7) && (long long)(N / 128) * ((M_est + 255) / 256) < (long long)num_cus * 3 / 2) sel = 0;
+    if (force < 0 && (sel == 4 || sel == 6 || sel == 7) && (long long)(N / 128) * ((M_est + 255) / 256) < (long long)num_cus * 3 / 2) sel = 0;
     if (res_added) *res_added = true;
     const long long p_tiles = (long long)(N / 128) * ((M_est + 255) / 256);
-    if ((sel == 4 || sel == 5 || sel == 6 || sel == 7 || (sel == 0 && p_tiles >= (long long)num_cus * 3 / 2)) && N % 128 == 0 && N <= kPersistBiasMax) {
+    if ((sel == 4 || sel == 6 || sel == 7 || (sel == 0 && p_tiles >= (long long)num_cus * 3 / 2)) && N % 128 == 0 && N <= kPersistBiasMax) {
         if (res_added) *res_added = false;
         else if (EPI == EPI_BIAS_RES_F32) return set_error(MDR_E_STATE, "large-M GEMM with a residual needs the caller to take the residual (res_added)");
         constexpr int E = EPI == EPI_BIAS_RES_F32 ? EPI_BIAS_F32 : EPI;
         // Both kernels are bound by the bytes a CU moves over its L2 path, loads AND stores (~20 B/clk/CU measured; skipping
         // the stores made the K = 768 GEMMs 25-30 % faster, deferring them did not): cost = rounds x (tile inputs + outputs).
-        // gemm_duo_kernel (256x128 tiles, the epilogue of a tile inside the next tile's K-loop) where a workgroup gets at least two tiles and an
-        // output tile is only 12 K-tiles long (K = 768: QKV, out-projection); MDR_GEMM_CFG=60 = the heuristic without it (A/B runs)
-        if ((sel == 5 || (sel == 0 && !no_duo && K == 768 && persistent_rounds(M_est, 256, N, 128, num_cus / 8) >= 2)) && duo_has<E>(K))
-            return launch_gemm_duo<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
         if (sel == 7 && N % 256 == 0 && K % 128 == 0 && K >= 256) return launch_gemm_quad<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
         if ((sel == 6 || sel == 0) && N % 256 == 0) {
             const double osz = (E == EPI_BIAS_F32) ? 4.0 : 2.0;
@@ -377,9 +346,9 @@ int mdr_test_gemm_f16(const void* A_dev, const void* W_dev, const float* bias_de
     MDR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "bad GEMM shape M=%d N=%d K=%d (N, K multiples of 64)", M, N, K);
     MDR_REQUIRE(epilogue == EPI_BIAS_F16 || epilogue == EPI_BIAS_GELU_F16 || epilogue == EPI_BIAS_F32, "epilogue must be 0, 1 or 3");
 #ifdef MDR_GEMM_EXTRA_CFGS
-    MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 5 || kernel == 6 || kernel == 7 || (kernel >= 8 && kernel <= 13), "kernel must be 0, 1, 2, 4-7 or 8-13");
+    MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 6 || kernel == 7 || (kernel >= 8 && kernel <= 13), "kernel must be 0, 1, 2, 4, 6, 7 or 8-13");
 #else
-    MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 5 || kernel == 6 || kernel == 7, "kernel must be 0, 1, 2, 4, 5, 6 or 7");
+    MDR_REQUIRE(kernel == 0 || kernel == 1 || kernel == 2 || kernel == 4 || kernel == 6 || kernel == 7, "kernel must be 0, 1, 2, 4, 6 or 7");
 #endif
     DeviceGuard guard(device);
     if (!guard.ok) return set_error(MDR_E_HIP, "hipSetDevice(%d) failed", device);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gemm_quad_kernel and gemm_duo_kernel keep their accumulators in a[0:255] ACROSS inline-asm statements, so the compiler itself must never touch an AGPR in that
+"""gemm_quad_kernel keeps its accumulators in a[0:255] ACROSS inline-asm statements, so the compiler itself must never touch an AGPR in that
 kernel (no AGPR spill slots, no copies). Compiles csrc/mdr_encoder.hip to assembly and checks every gemm_quad_kernel instantiation:
 outside ;;#ASMSTART / ;;#ASMEND no instruction may name an AGPR, and nothing may spill to scratch. Exit code 0 = clean."""
 import os
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def check(asm_text):
     bad = []
     kernels = 0
-    for m in re.finditer(r"^(_Z\w*gemm_(?:quad|duo)_kernel\w*):[^\n]*\n(.*?)\n\s*s_endpgm", asm_text, re.S | re.M):
+    for m in re.finditer(r"^(_Z\w*gemm_quad_kernel\w*):[^\n]*\n(.*?)\n\s*s_endpgm", asm_text, re.S | re.M):
         kernels += 1
         inside = False
         for line in m.group(2).split("\n"):
@@ -36,10 +36,10 @@ def main():
                os.path.join(ROOT, "multihop_dense_retrieval_amd", "csrc", "mdr_encoder.hip"), "-o", out]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         kernels, bad = check(open(out).read())
-    print(f"{kernels} gemm_quad_kernel / gemm_duo_kernel instantiations, {len(bad)} compiler-generated AGPR / scratch instructions")
+    print(f"{kernels} gemm_quad_kernel instantiations, {len(bad)} compiler-generated AGPR / scratch instructions")
     for k, t in bad[:20]:
         print("  ", k[-40:], t)
-    return 0 if kernels >= 6 and not bad else 1
+    return 0 if kernels >= 3 and not bad else 1
 
 
 if __name__ == "__main__":

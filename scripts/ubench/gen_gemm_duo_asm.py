@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates multihop_dense_retrieval_amd/csrc/mdr_encoder_gemm_duo_loop.inc: the hand-scheduled K-loops of gemm_duo_kernel -- a persistent
+"""ARCHIVED EXPERIMENT (round 3, see mdr_encoder_gemm_duo.inl.txt beside this file). Generates mdr_encoder_gemm_duo_loop.inc: the hand-scheduled K-loops of gemm_duo_kernel -- a persistent
 256x128x64 f16 GEMM on four waves of 128x64 (one wave per SIMD), a THREE-slot LDS ring (48 KiB slots, a K-tile of extra DMA lead) and TWO
 accumulator sets, so that the epilogue of tile j-1 is woven into the K-loop of tile j (one wave per SIMD cannot hide an epilogue any other way;
 measured alone it costs 30-45 % of a K = 768 tile).

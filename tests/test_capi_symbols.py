@@ -3,6 +3,7 @@ include/mdr_hip.h declares (no compute calls here)."""
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -111,3 +112,19 @@ def test_docs_cite_tests_and_files_that_exist():
             if not os.path.exists(os.path.join(ROOT, path)):
                 missing.append(f"{doc}: {path}")
     assert not missing, missing
+
+
+def test_hand_scheduled_gemm_keeps_its_accumulators_to_itself():
+    """gemm_quad_kernel leaves its accumulators in a[0:255] across inline-asm statements; the compiler must not touch an AGPR or spill in that
+    kernel (scripts/check_quad_agprs.py compiles csrc/mdr_encoder.hip to assembly and reads every instantiation)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_quad_agprs.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_generated_k_loop_is_what_the_generator_writes():
+    """csrc/mdr_encoder_gemm_quad_loop.inc is generated; the committed file must be the generator's output."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_gemm_quad_asm.py")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    assert r.stdout == open(os.path.join(ROOT, "multihop_dense_retrieval_amd", "csrc", "mdr_encoder_gemm_quad_loop.inc")).read()

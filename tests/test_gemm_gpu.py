@@ -37,7 +37,7 @@ SHAPES = [  # (M, N, K): encoder shapes incl. ragged M, one tile, many tiles per
 ]
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 4, 5, 6, 7])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 4, 6, 7])
 @pytest.mark.parametrize("epilogue", [0, 1, 3])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gemm_matches_fp64(shape, epilogue, kernel):
@@ -56,19 +56,6 @@ def test_gemm_matches_fp64(shape, epilogue, kernel):
     assert not bool(bad.any()), f"{int(bad.sum())} bad of {M * N}; worst {err.max().item():.3e} at {np.unravel_index(int(err.argmax()), (M, N))}"
 
 
-def test_duo_kernel_is_bit_identical_to_the_eight_wave_kernel():
-    """Kernel 5 (256x128 tiles, two accumulator sets, the epilogue of a tile inside the next tile's K-loop): same MFMA, same K order, same
-    rounding -- for one tile per workgroup (no woven epilogue at all), two, and many, ragged M, both output types, K = 768 and 3072."""
-    for (M, N, K), epi in (((20297, 2304, 768), 0), ((20297, 768, 768), 3), ((20297, 768, 3072), 3), ((700, 768, 768), 3), ((65536, 2304, 768), 0),
-                           ((40000, 768, 3072), 3), ((2413, 3072, 768), 0), ((33000, 768, 768), 0)):
-        g = torch.Generator(device="cuda").manual_seed(11)
-        A = torch.randn((M, K), generator=g, device="cuda").half()
-        W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).half()
-        bias = torch.randn((N,), generator=g, device="cuda")
-        a, b = _gemm(A, W, bias, epi, 6), _gemm(A, W, bias, epi, 5)
-        assert torch.equal(a, b), f"{(M, N, K)} epilogue {epi}: {(a.double() - b.double()).abs().max().item():.3e} at {int((a != b).sum())} places"
-
-
 def test_quad_kernel_is_bit_identical_to_the_eight_wave_kernel():
     """Kernel 7 (four waves of 128x128, hand-scheduled K-loop) accumulates K in the same order with the same MFMA as kernel 6."""
     for (M, N, K), epi in (((20611, 2304, 768), 0), ((9000, 3072, 768), 1), ((20611, 768, 3072), 3), ((2413, 768, 768), 3)):
@@ -80,7 +67,7 @@ def test_quad_kernel_is_bit_identical_to_the_eight_wave_kernel():
         assert torch.equal(a, b), f"{(M, N, K)} epilogue {epi}: {(a.double() - b.double()).abs().max().item():.3e}"
 
 
-@pytest.mark.parametrize("kernel", [0, 4, 5, 6, 7])
+@pytest.mark.parametrize("kernel", [0, 4, 6, 7])
 def test_gemm_device_side_row_count(kernel):
     """Rows past *m_dev are neither computed into nor stored (the packed token count lives on the device)."""
     M, N, K, valid = 5000, 768, 768, 3333
