@@ -45,6 +45,22 @@ __device__ inline f32x4 gelu_erf4(f32x4 x) {
     return (f32x4){lo[0], lo[1], hi[0], hi[1]};
 }
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// the epilogues' LDS scratch is written as halves or floats and read back as raw 16-byte chunks by OTHER lanes: accesses through these types may
+// alias anything, so the compiler keeps a block's reads in front of the next block's writes (with plain vector types it is free to swap them)
+typedef u32x2 __attribute__((may_alias)) scr_u32x2;
+typedef u32x4 __attribute__((may_alias)) scr_u32x4;
+typedef f32x4 __attribute__((may_alias)) scr_f32x4;
+// four floats -> four halves (round to nearest even, what (_Float16)x does) as two v_cvt_pk_f16_f32. Through __builtin_convertvector, NOT inline asm:
+// gfx950 needs a wait state between a VALU write and a v_cvt_pk_f16_f32 that reads it, which hipcc inserts for its own instructions only (an asm
+// version returned wrong halves in ~0.05 % of the outputs).
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ inline u32x2 cvt_pk_half4(f32x4 v) {
+    const half2v lo = __builtin_convertvector((f32x2){v[0], v[1]}, half2v), hi = __builtin_convertvector((f32x2){v[2], v[3]}, half2v);
+    return (u32x2){__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+}
+
 template <int BM_, int BN_, int WGM_, int WGN_, int STAGES_>
 struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, STAGES = STAGES_;
@@ -440,6 +456,8 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* lds_bias = (float*)(lds + C::LDS_BYTES);
     const int M = M_dev ? min(*M_dev, M_cap) : M_cap;
+    // output descriptor: raw buffer over rows [0, M) -- stores to rows past M (the last, partial row tile) are dropped by its bounds check
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(((unsigned)(M - 1) * (unsigned)ldo + (unsigned)N) * ((EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) ? 2u : 4u)), 0x00020000);
     const int ntn = N / 256, ntm = (M + 255) / 256;
     const long long T_all = (long long)ntm * ntn;  // tile order and XCD ownership: see gemm_persist_kernel
     const int xcd = blockIdx.x & 7;
@@ -596,44 +614,53 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
             // tile cost the CU ~25 % of a K = 768 GEMM (measured by skipping them; they are line-REQUEST bound, not byte bound:
             // deferring them over the next K-steps did not help). So each 16-row block goes through a 2 KiB per-wave LDS
             // scratch (16-B chunks XOR-swizzled by row & 7) and leaves as 8 rows x 128 B = 8 full lines per instruction.
+            // Round 3: the bias of the wave's 64 columns is read ONCE per tile (hipcc re-read it from LDS in front of every fragment and
+            // waited for it each time), the halves are packed by v_cvt_pk_f16_f32 (it emitted 7 instructions per 4 values), and the rows
+            // leave through a buffer descriptor whose bounds check (on the VGPR offset) drops the rows past M: no per-row predicate, no 64-bit address
+            // arithmetic, and with the branches gone the two reads and two stores of a block are issued together.
             char* scr = lds + C::LDS_BYTES + kPersistBiasMax * 4 + wave * 2048;
             const int rd_row = lane >> 3, rd_chunk = lane & 7;
             constexpr bool F16OUT = EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16;
+            constexpr unsigned OB = F16OUT ? 2u : 4u;
+            f32x4 b4[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) b4[nt] = *(const f32x4*)(lds_bias + n0 + wc * 64 + nt * 16 + 4 * g);
+            // (the descriptor's bounds check covers the VGPR offset only, not the scalar one: the ROW goes into the VGPR, the column base into the SGPR)
+            const unsigned o_col = __builtin_amdgcn_readfirstlane((unsigned)(n0 + wc * 64) * OB);
+            const unsigned o_lane = (unsigned)(m0 + wr * 128 + rd_row) * (unsigned)ldo * OB + (unsigned)rd_chunk * 16u;
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
-                const int mrow = m0 + wr * 128 + mt * 16;
 #pragma unroll
                 for (int hf = 0; hf < (F16OUT ? 1 : 2); ++hf) {  // f32 rows of 64 columns take two 128-B passes
 #pragma unroll
                     for (int q = 0; q < (F16OUT ? 4 : 2); ++q) {
                         const int nt = F16OUT ? q : 2 * hf + q;
-                        const int n = n0 + wc * 64 + nt * 16 + 4 * g;
-                        const f32x4 b4 = *(const f32x4*)(lds_bias + n);
-                        f32x4 v = acc[mt][nt] + b4;
+                        f32x4 v = acc[mt][nt] + b4[nt];
                         if (EPI == EPI_BIAS_GELU_F16) {
                             v = gelu_erf4(v);
                         }
                         if constexpr (F16OUT) {
-                            half4 o;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
-                            *(half4*)(scr + lr * 128 + (((q * 2 + (g >> 1)) ^ (lr & 7)) << 4) + (g & 1) * 8) = o;
+                            *(scr_u32x2*)(scr + lr * 128 + (((q * 2 + (g >> 1)) ^ (lr & 7)) << 4) + (g & 1) * 8) = cvt_pk_half4(v);
                         } else {
-                            *(f32x4*)(scr + lr * 128 + (((q * 4 + g) ^ (lr & 7)) << 4)) = v;
+                            *(scr_f32x4*)(scr + lr * 128 + (((q * 4 + g) ^ (lr & 7)) << 4)) = v;
                         }
                     }
                     // row r = rd_row (+8), 16-B chunk rd_chunk of the 128-B row block
+                    u32x4 val[2];
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         const int r = rd_row + 8 * half;
-                        const f32x4 val = *(const f32x4*)(scr + r * 128 + ((rd_chunk ^ (r & 7)) << 4));
-                        const int m = mrow + r;
-                        if (ABL == 4) { asm volatile("" ::"v"(val)); continue; }
-                        if (m < M) {
-                            if constexpr (F16OUT) *(f32x4*)((_Float16*)out + (size_t)m * ldo + n0 + wc * 64 + rd_chunk * 8) = val;
-                            else *(f32x4*)((float*)out + (size_t)m * ldo + n0 + wc * 64 + hf * 32 + rd_chunk * 4) = val;
-                        }
+                        val[half] = *(const scr_u32x4*)(scr + r * 128 + ((rd_chunk ^ (r & 7)) << 4));
                     }
+                    if (ABL == 4) { asm volatile("" ::"v"(val[0]), "v"(val[1])); continue; }
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+                        __builtin_amdgcn_raw_buffer_store_b128(val[half], out_rsrc, o_lane + (unsigned)(mt * 16 + 8 * half) * (unsigned)ldo * OB, o_col + (unsigned)hf * 128u, 0);
+                    // A 16-byte buffer store reads its data registers over several cycles; hipcc's hazard recogniser assumes that a store with an
+                    // SGPR offset is exempt and lets the next block's first v_pk_add overwrite them straight away -- on gfx950 that corrupted the last
+                    // dword of lanes 12-15 of every 16 (found as wrong values in odd rows of the last column of a chunk). Three wait states, with the
+                    // data as operands of the asm so that the registers stay untouched until they have passed.
+                    asm volatile("s_nop 2" ::"v"(val[0]), "v"(val[1]) : "memory");
                 }
             }
         }

@@ -29,26 +29,20 @@ __device__ __forceinline__ f32x4 quad_acc_tile() {
     return (f32x4){quad_acc_read<B>(), quad_acc_read<B + 1>(), quad_acc_read<B + 2>(), quad_acc_read<B + 3>()};
 }
 
-// one 16-row block (m-fragment MT) of the wave's 128 columns: bias (+ GELU), through the per-wave LDS scratch, out as full 128-B lines
+// one 16-row block (m-fragment MT) of the wave's 128 columns: bias (+ GELU), through the per-wave LDS scratch, out as full 128-B lines through a
+// buffer descriptor (rows past M dropped by its bounds check, which covers the VGPR offset only: o_lane carries the row, o_col the column base); b8 = the bias of the 128 columns, read once per tile
 template <int EPI, int MT>
-__device__ __forceinline__ void quad_epilogue_rows(char* scr, const float* lds_bias, void* __restrict__ out, int ldo, int M, int mrow, int ncol0, int g,
-                                                   int lr) {
+__device__ __forceinline__ void quad_epilogue_rows(char* scr, const f32x4 (&b8)[8], __amdgpu_buffer_rsrc_t out_rsrc, unsigned o_col, unsigned o_lane, unsigned ldo_b,
+                                                   int g, int lr) {
     constexpr bool F16OUT = EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16;
 #pragma unroll
     for (int hf = 0; hf < (F16OUT ? 1 : 2); ++hf) {
         auto put = [&](auto ntc, int q) __attribute__((always_inline)) {
             constexpr int NT = decltype(ntc)::value;
-            const f32x4 b4 = *(const f32x4*)(lds_bias + ncol0 + NT * 16 + 4 * g);
-            f32x4 v = quad_acc_tile<MT, NT>() + b4;
+            f32x4 v = quad_acc_tile<MT, NT>() + b8[NT];
             if (EPI == EPI_BIAS_GELU_F16) v = gelu_erf4(v);
-            if constexpr (F16OUT) {
-                half4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
-                *(half4*)(scr + lr * 256 + (((q * 2 + (g >> 1)) ^ lr) << 4) + (g & 1) * 8) = o;
-            } else {
-                *(f32x4*)(scr + lr * 256 + (((q * 4 + g) ^ lr) << 4)) = v;
-            }
+            if constexpr (F16OUT) *(scr_u32x2*)(scr + lr * 256 + (((q * 2 + (g >> 1)) ^ lr) << 4) + (g & 1) * 8) = cvt_pk_half4(v);
+            else *(scr_f32x4*)(scr + lr * 256 + (((q * 4 + g) ^ lr) << 4)) = v;
         };
         if constexpr (F16OUT) {
             put(std::integral_constant<int, 0>{}, 0); put(std::integral_constant<int, 1>{}, 1); put(std::integral_constant<int, 2>{}, 2);
@@ -62,20 +56,19 @@ __device__ __forceinline__ void quad_epilogue_rows(char* scr, const float* lds_b
             put(std::integral_constant<int, 7>{}, 3);
         }
         // 4 passes of 4 rows x 256 B: row = 4 pass + (lane >> 4), 16-B chunk lane & 15
+        u32x4 val[4];
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int r = 4 * ps + g;
-            const f32x4 val = *(const f32x4*)(scr + r * 256 + ((lr ^ r) << 4));
-            const int m = mrow + r;
-#if defined(MDR_QUAD_ABL) && MDR_QUAD_ABL == 2  // measurement build: everything but the global stores
-            asm volatile("" ::"v"(val));
-            continue;
-#endif
-            if (m < M) {
-                if constexpr (F16OUT) *(f32x4*)((_Float16*)out + (size_t)m * ldo + ncol0 + lr * 8) = val;
-                else *(f32x4*)((float*)out + (size_t)m * ldo + ncol0 + hf * 64 + lr * 4) = val;
-            }
+            val[ps] = *(const scr_u32x4*)(scr + r * 256 + ((lr ^ r) << 4));
         }
+#if defined(MDR_QUAD_ABL) && MDR_QUAD_ABL == 2  // measurement build: everything but the global stores
+        asm volatile("" ::"v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]));
+        continue;
+#endif
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) __builtin_amdgcn_raw_buffer_store_b128(val[ps], out_rsrc, o_lane + (unsigned)(MT * 16 + 4 * ps) * ldo_b, o_col + (unsigned)hf * 256u, 0);
+        asm volatile("s_nop 2" ::"v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]) : "memory");  // store-data hazard hipcc does not cover for SGPR-offset stores: see gemm_big_kernel
     }
 }
 
@@ -112,7 +105,6 @@ gemm_quad_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __rest
     const unsigned ld_chunk = (unsigned)(((tid & 7) ^ (ld_row & 7)) * 16);
     const unsigned offa0 = (unsigned)ld_row * (unsigned)lda * 2u + ld_chunk, offw0 = (unsigned)ld_row * (unsigned)K * 2u + ld_chunk;
     const unsigned rsa = __builtin_amdgcn_readfirstlane(64u * (unsigned)lda), rsw = __builtin_amdgcn_readfirstlane(64u * (unsigned)K);  // 32 rows, bytes
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto make_srd = [](const void* p, unsigned bytes) __attribute__((always_inline)) {
         const unsigned long long a = (unsigned long long)p;
         u32x4 r;
@@ -124,6 +116,8 @@ gemm_quad_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __rest
     };
     const u32x4 srda = make_srd(A, ((unsigned)(M - 1) * (unsigned)lda + (unsigned)K) * 2u);
     const u32x4 srdw = make_srd(W, (unsigned)N * (unsigned)K * 2u);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        out, 0, (int)(((unsigned)(M - 1) * (unsigned)ldo + (unsigned)N) * ((EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) ? 2u : 4u)), 0x00020000);
     const unsigned rda = (unsigned)((wr * 128 + lr) * 128 + ((g ^ (lane & 7)) << 4));
     const unsigned rdw = (unsigned)(C::A_BYTES + (wc * 128 + lr) * 128 + ((g ^ (lane & 7)) << 4));
     const unsigned dst0 = (unsigned)(wave * 1024);
@@ -153,18 +147,24 @@ gemm_quad_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __rest
         // Epilogue under the loads in flight (K-tile 0 and the first pieces of K-tile 1 of the next tile), through a 4 KiB per-wave LDS
         // scratch so that every store instruction writes full 128-B lines (see gemm_big_kernel): a 16-row block of the wave's 128
         // columns = 16 x 256 B (f16) or two halves of 16 x 64 columns x 4 B (f32); 16-B chunks XOR-swizzled by the row.
-        const int mrow = m0 + wr * 128, ncol0 = n0 + wc * 128;
+        constexpr unsigned OB = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) ? 2u : 4u;
 #if defined(MDR_QUAD_ABL) && MDR_QUAD_ABL == 1  // measurement build: no epilogue (results wrong)
         continue;
 #endif
-        quad_epilogue_rows<EPI, 0>(scr, lds_bias, out, ldo, M, mrow + 0, ncol0, g, lr);
-        quad_epilogue_rows<EPI, 1>(scr, lds_bias, out, ldo, M, mrow + 16, ncol0, g, lr);
-        quad_epilogue_rows<EPI, 2>(scr, lds_bias, out, ldo, M, mrow + 32, ncol0, g, lr);
-        quad_epilogue_rows<EPI, 3>(scr, lds_bias, out, ldo, M, mrow + 48, ncol0, g, lr);
-        quad_epilogue_rows<EPI, 4>(scr, lds_bias, out, ldo, M, mrow + 64, ncol0, g, lr);
-        quad_epilogue_rows<EPI, 5>(scr, lds_bias, out, ldo, M, mrow + 80, ncol0, g, lr);
-        quad_epilogue_rows<EPI, 6>(scr, lds_bias, out, ldo, M, mrow + 96, ncol0, g, lr);
-        quad_epilogue_rows<EPI, 7>(scr, lds_bias, out, ldo, M, mrow + 112, ncol0, g, lr);
+        f32x4 b8[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) b8[nt] = *(const f32x4*)(lds_bias + n0 + wc * 128 + nt * 16 + 4 * g);
+        const unsigned ldo_b = (unsigned)ldo * OB;
+        const unsigned o_col = __builtin_amdgcn_readfirstlane((unsigned)(n0 + wc * 128) * OB);
+        const unsigned o_lane = (unsigned)(m0 + wr * 128 + g) * ldo_b + (unsigned)lr * 16u;
+        quad_epilogue_rows<EPI, 0>(scr, b8, out_rsrc, o_col, o_lane, ldo_b, g, lr);
+        quad_epilogue_rows<EPI, 1>(scr, b8, out_rsrc, o_col, o_lane, ldo_b, g, lr);
+        quad_epilogue_rows<EPI, 2>(scr, b8, out_rsrc, o_col, o_lane, ldo_b, g, lr);
+        quad_epilogue_rows<EPI, 3>(scr, b8, out_rsrc, o_col, o_lane, ldo_b, g, lr);
+        quad_epilogue_rows<EPI, 4>(scr, b8, out_rsrc, o_col, o_lane, ldo_b, g, lr);
+        quad_epilogue_rows<EPI, 5>(scr, b8, out_rsrc, o_col, o_lane, ldo_b, g, lr);
+        quad_epilogue_rows<EPI, 6>(scr, b8, out_rsrc, o_col, o_lane, ldo_b, g, lr);
+        quad_epilogue_rows<EPI, 7>(scr, b8, out_rsrc, o_col, o_lane, ldo_b, g, lr);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus pieces must have landed before the LDS is released
 }

@@ -13,7 +13,7 @@ Register map (per wave; the clobber list of the asm statements):
   v[0:31]    A fragments of k-half 0, v[32:63] W fragments of k-half 0, v[64:95] / v[96:127] the same for k-half 1
   v128/v129  LDS read address of A / W, k-half 0 (slot included); v130/v131 k-half 1
   v[132:139] buffer offsets of the wave's 8 A pieces, v[140:147] of its 8 W pieces
-  s20 / s21  scalar buffer offset of the loader's K-tile in A / W; s24 loop counter; s25 LDS destination of piece 0 (wave and slot included)
+  s20 / s21  scalar buffer offset of the loader's K-tile in A (K position only: the rows are in v[132:139]) / W; s24 loop counter; s25 LDS destination of piece 0 (wave and slot included)
 One step = one K-tile: phase 0 (64 MFMAs on k-half 0; reads k-half 1 of the same slot) | s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier (slot free,
 next K-tile landed) | phase 1 (64 MFMAs on k-half 1; reads k-half 0 of the next K-tile from the other slot). The DMA pieces of K-tile T+2 are
 issued right behind the barrier of step T (`sched`: pieces per 16-MFMA sub-phase, 4 of phase 1 then 4 of the next phase 0).
@@ -82,7 +82,10 @@ def step(emit, zero_c=False, switch=False, last=False):
     emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
     emit("s_barrier")
     if switch:  # the loader leaves this tile: K-tile 0 of the next one
-        emit("s_mov_b32 s20, %[nexta]")
+        emit("s_sub_u32 s20, %[nexta], %[soffa]")
+        for c in range(8):
+            emit(f"v_add_u32 v{132 + c}, s20, v{132 + c}")
+        emit("s_mov_b32 s20, 0")
         emit("s_mov_b32 s21, %[nextw]")
     else:
         emit("s_add_u32 s20, s20, 128")
@@ -100,7 +103,9 @@ def setup(emit):
     emit("v_mov_b32 v129, %[rdw]")
     emit("v_xor_b32 v130, 64, v128")  # k-half 1 = 16-byte chunk index ^ 4
     emit("v_xor_b32 v131, 64, v129")
-    emit("v_mov_b32 v132, %[offa0]")
+    # the descriptor's bounds check covers the VGPR offset only: the tile's ROWS of A go into it (rows past M then read as zeros wherever the
+    # scalar offset stands), the scalar offset s20 carries the K position alone; W rows are always in range, its tile base stays scalar
+    emit("v_add_u32 v132, %[soffa], %[offa0]")
     for c in range(1, 8):
         emit(f"v_add_u32 v{132 + c}, %[rsa], v{131 + c}")
     emit("v_mov_b32 v140, %[offw0]")
@@ -119,7 +124,7 @@ def as_c_string(name, lines):
 # ---- prologue of a workgroup's first tile: K-tile 0 completely + the first pieces of K-tile 1, then wait for K-tile 0 and meet
 pro = []
 setup(pro.append)
-pro.append("s_mov_b32 s20, %[soffa]")
+pro.append("s_mov_b32 s20, 0")
 pro.append("s_mov_b32 s21, %[soffw]")
 pro.append("s_mov_b32 s25, %[dst0]")
 for c in range(16):
@@ -136,7 +141,7 @@ pro.append("s_barrier")
 body = []
 e = body.append
 setup(e)
-e("s_add_u32 s20, %[soffa], 128")
+e("s_mov_b32 s20, 128")
 e("s_add_u32 s21, %[soffw], 128")
 e("s_xor_b32 s25, %[dst0], 0x10000")
 e("s_mov_b32 s24, %[iters]")
