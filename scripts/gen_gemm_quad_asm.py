@@ -44,6 +44,7 @@ def frag(buf, kind, i):  # kind 0 = A, 1 = W
 def piece(c):
     const = (0 if c < 8 else 32768) + (c & 7) * 4096
     return [f"s_add_u32 m0, s25, {const}",
+            "s_nop 0",  # an SALU write of M0 needs one wait state before the LDS-DMA that reads it (hipcc inserts the same s_nop for its builtin)
             f"buffer_load_dwordx4 v{132 + c}, {'%[srda]' if c < 8 else '%[srdw]'}, {'s20' if c < 8 else 's21'} offen lds"]
 
 

@@ -48,6 +48,7 @@ def frag(buf, kind, i):  # kind 0 = A, 1 = W
 def piece(c, slot):
     const = slot * SLOT + (0 if c < 8 else 32768) + (c & 7) * 4096
     return [f"s_add_u32 m0, s25, {const}",
+            "s_nop 0",
             f"buffer_load_dwordx4 v{108 + c}, {'%[srda]' if c < 8 else '%[srdw]'}, {'s20' if c < 8 else 's21'} offen lds"]
 
 

@@ -51,7 +51,7 @@ def piece(c):
     const = (0 if c < 8 else 32768) + (c & 7) * 4096
     if args.no_dma:
         return []
-    return [f"s_add_u32 m0, s25, {const}", f"global_load_lds_dwordx4 v{132 + c}, {'s[20:21]' if c < 8 else 's[22:23]'}"]
+    return [f"s_add_u32 m0, s25, {const}", "s_nop 0", f"global_load_lds_dwordx4 v{132 + c}, {'s[20:21]' if c < 8 else 's[22:23]'}"]
 
 
 def phase(h):
