@@ -559,6 +559,24 @@ def main():
                                 "stage_ms": pipe_q.stage_ms(), "mips_roofline": mips_roofline(pipe_q, local, args, d)}
         del pipe_q
 
+    if pipe.pipelined and pipe.use_encoder and world == 1 and not args.no_sequential and not getattr(pipe.encoder, "residual_fp32", False):
+        # the same job with the apex-O1-faithful fp32 residual stream (a numerics MODE of the encoder, off by default: DESIGN.md section 4): what the
+        # headline would be with it, and how far the two modes' embeddings are apart -- a sub-result of the same line
+        from multihop_dense_retrieval_amd.retriever import RobertaRetriever
+        enc32 = RobertaRetriever.random_init(device=device, seed=3)
+        enc32.residual_fp32 = True
+        mhop.SyntheticTwoHop._defer_encoder = True
+        pipe_r = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
+                                      max_q_sp_len=args.max_q_sp_len, use_encoder=True, planted_rows=rows_sum, rank=rank, world=world, weak=weak, pipelined=True)
+        mhop.SyntheticTwoHop._defer_encoder = False
+        pipe_r.encoder, pipe_r.arena = enc32, pipe.arena
+        out_r, el_r = timed_steps(pipe_r, args, world, device, dist)
+        result["residual_fp32"] = {"value": round(GB * args.steps / el_r, 2), "unit": "queries/s", "ms_per_step": round(el_r / args.steps * 1e3, 4),
+                                   "hop1_embedding_max_abs_diff_vs_default": round(float((out_r["q"] - out["q"]).abs().max()), 6),
+                                   "hop1_ids_equal_to_default": bool((out_r["I"] == out["I"]).all()),
+                                   "note": "encoder.residual_fp32 = 1: LayerNorm outputs stay fp32 for the residual adds (what apex O1 does); the default rounds them to fp16"}
+        del pipe_r, enc32
+
     if world > 1 and weak and not args.no_strong:
         # The same job with ONE 100-question batch shared by all ranks (the reference's fixed --batch-size): a sub-result of
         # the same JSON line, so a scaling run carries the strong-scaling number next to the weak one.

@@ -34,6 +34,7 @@ print("enc", {k: r["roofline_encoder"][k] for k in ("achieved", "frac", "frac_of
 print("seq", r["sequential"]["value"], r["sequential"]["stage_ms"], r["sequential"]["mips_roofline"]["frac"])
 print("cpu", r["cpu_baseline"]["value"], r["cpu_baseline"]["cores"], r["cpu_baseline"]["top1_id_agreement_with_hip_index"])
 print("aniso", json.dumps(r.get("anisotropic"))[:600])
+print("residual_fp32", r.get("residual_fp32"))
 print("self_check", r["self_check"]["full_size_exact"], r.get("mips_tiers"))
 PY
 

@@ -34,6 +34,8 @@ def _reference(A, W, bias, epilogue):
 SHAPES = [  # (M, N, K): encoder shapes incl. ragged M, one tile, many tiles per workgroup
     (187, 768, 768), (256, 2304, 768), (1000, 3072, 768), (2413, 768, 3072), (20611, 2304, 768), (33000, 768, 768), (9000, 3072, 768),
     (9000, 768, 3072), (70000, 768, 768),
+    # shapes outside roberta-base: K of 4 and 6 K-tiles (the four-wave kernel's shortest loops), N = 256, roberta-large's 1024
+    (300, 256, 256), (5000, 512, 384), (3000, 1024, 1024),
 ]
 
 
