@@ -563,8 +563,16 @@ def main():
         # the same job with the apex-O1-faithful fp32 residual stream (a numerics MODE of the encoder, off by default: DESIGN.md section 4): what the
         # headline would be with it, and how far the two modes' embeddings are apart -- a sub-result of the same line
         from multihop_dense_retrieval_amd.retriever import RobertaRetriever
-        enc32 = RobertaRetriever.random_init(device=device, seed=3)
-        enc32.residual_fp32 = True
+        prev = os.environ.get("MDR_RESIDUAL_FP32")
+        os.environ["MDR_RESIDUAL_FP32"] = "1"  # read when the encoder object is made (the device handle is created with the mode)
+        try:
+            enc32 = RobertaRetriever.random_init(device=device, seed=3)
+        finally:
+            if prev is None:
+                del os.environ["MDR_RESIDUAL_FP32"]
+            else:
+                os.environ["MDR_RESIDUAL_FP32"] = prev
+        assert enc32.residual_fp32
         mhop.SyntheticTwoHop._defer_encoder = True
         pipe_r = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
                                       max_q_sp_len=args.max_q_sp_len, use_encoder=True, planted_rows=rows_sum, rank=rank, world=world, weak=weak, pipelined=True)
