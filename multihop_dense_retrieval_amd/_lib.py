@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDR_LIB_PATH") or os.path.join(_HERE, "libmdrhip.so")
 
 MDR_DT_F32, MDR_DT_BF16, MDR_DT_F16 = 0, 1, 2
-MDR_STORE_F32X2H, MDR_STORE_BF16 = 0, 1
+MDR_STORE_F32X2H, MDR_STORE_BF16, MDR_STORE_F32X2H_COMPACT = 0, 1, 2
 
 
 class MdrError(RuntimeError):

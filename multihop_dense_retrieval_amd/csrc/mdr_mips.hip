@@ -72,6 +72,7 @@ struct mdr_index {
     void* stage = nullptr;   // device staging for host-sourced add()
     size_t stage_bytes = 0;
     int variant = 0;
+    bool compact = false;    // MDR_STORE_F32X2H_COMPACT: no int8 screening plane
     const char* last_kernel = "none";
 };
 
@@ -86,7 +87,7 @@ long long pad32(long long n) { return (n + 31) / 32 * 32; }
 // the int8 screening plane exists for the storage / dimension the k = 1 screen path serves; MDR_MIPS_I8=0 (read at index creation) leaves it out
 bool wants_i8(const mdr_index* h) {
     static const bool off = getenv("MDR_MIPS_I8") && atoi(getenv("MDR_MIPS_I8")) == 0;
-    return !off && h->storage != MDR_STORE_BF16 && h->d == 768;
+    return !off && !h->compact && h->storage != MDR_STORE_BF16 && h->d == 768;
 }
 
 int grow(mdr_index* h, long long need_rows, hipStream_t st) {
@@ -580,7 +581,7 @@ extern "C" {
 int mdr_index_create(int d, int storage, int device, mdr_index** out) {
     MDR_REQUIRE(out != nullptr, "out is NULL");
     MDR_REQUIRE(d > 0 && d % 32 == 0 && d <= 1024, "d=%d unsupported: must be a multiple of 32, <= 1024", d);
-    MDR_REQUIRE(storage == MDR_STORE_F32X2H || storage == MDR_STORE_BF16, "unknown storage %d", storage);
+    MDR_REQUIRE(storage == MDR_STORE_F32X2H || storage == MDR_STORE_BF16 || storage == MDR_STORE_F32X2H_COMPACT, "unknown storage %d", storage);
     int ndev = 0;
     MDR_HIP_TRY(hipGetDeviceCount(&ndev));
     MDR_REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
@@ -590,7 +591,8 @@ int mdr_index_create(int d, int storage, int device, mdr_index** out) {
     MDR_REQUIRE(h != nullptr, "out of host memory");
     h->d = d;
     h->nkb = d / 32;
-    h->storage = storage;
+    h->storage = storage == MDR_STORE_F32X2H_COMPACT ? MDR_STORE_F32X2H : storage;
+    h->compact = storage == MDR_STORE_F32X2H_COMPACT;
     h->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;

@@ -24,10 +24,14 @@ class IndexFlatIP:
     """Brute-force maximum-inner-product index resident in HBM."""
 
     def __init__(self, d, device=None, storage=_lib.MDR_STORE_F32X2H):
-        """storage: MDR_STORE_F32X2H (default; fp32-accurate, 4 B/element) or MDR_STORE_BF16 / "bf16" (rows rounded to bf16,
-        2 B/element; scores are exact w.r.t. the rounded rows, i.e. within 1e-2 of the fp32 scores for unit-scale data)."""
+        """storage: MDR_STORE_F32X2H (default; fp32-accurate, 4 B/element + at d = 768 a 1 B/element int8 screening copy that makes k = 1
+        searches ~1.5 x faster), MDR_STORE_F32X2H_COMPACT / "compact" (the same without that copy: faiss.IndexFlatIP's 4 B/element, same
+        results) or MDR_STORE_BF16 / "bf16" (rows rounded to bf16, 2 B/element; scores are exact w.r.t. the rounded rows, i.e. within 1e-2 of
+        the fp32 scores for unit-scale data)."""
         if storage in ("bf16", "BF16"):
             storage = _lib.MDR_STORE_BF16
+        elif storage in ("compact", "f32-compact"):
+            storage = _lib.MDR_STORE_F32X2H_COMPACT
         if not torch.cuda.is_available():
             raise RuntimeError("IndexFlatIP needs a HIP device (there is no CPU fallback)")
         self.d = int(d)

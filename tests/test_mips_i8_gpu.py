@@ -130,6 +130,34 @@ def test_env_switch_leaves_the_plane_out(mdr, monkeypatch):
     assert "mips_screen8_kernel" in idx.last_kernel()
 
 
+def test_compact_storage_is_the_same_index_without_the_plane(mdr):
+    """MDR_STORE_F32X2H_COMPACT: FAISS's 4 bytes per element, no int8 screening copy; the ids of the default storage, scores from the same exact re-scoring."""
+    g = torch.Generator(device="cuda").manual_seed(12)
+    x = torch.randn((40000, D_), generator=g, device="cuda")
+    q = torch.randn((100, D_), generator=g, device="cuda")
+    a, b = mdr.IndexFlatIP(D_), mdr.IndexFlatIP(D_, storage="compact")
+    a.add(x)
+    b.add(x)
+    for k in (1, 4):
+        Da, Ia = a.search(q, k)
+        Db, Ib = b.search(q, k)
+        assert torch.equal(torch.as_tensor(Ia), torch.as_tensor(Ib))
+        Da, Db = torch.as_tensor(Da), torch.as_tensor(Db)
+        assert torch.equal(Da, Db) or float((Da - Db).abs().max()) <= 2e-6 * float(Da.abs().max())
+    b.search(q, 1)
+    assert "mips_screen_kernel" in b.last_kernel() and not b.telemetry(100, 1)["i8_tier"]
+    a.search(q, 1)
+    assert a.telemetry(100, 1)["i8_tier"]
+    free0 = torch.cuda.mem_get_info()[0]
+    c = mdr.IndexFlatIP(D_, storage="compact")
+    c.reserve(1_000_000)
+    used_compact = free0 - torch.cuda.mem_get_info()[0]
+    d = mdr.IndexFlatIP(D_)
+    d.reserve(1_000_000)
+    used_default = free0 - used_compact - torch.cuda.mem_get_info()[0]
+    assert used_compact <= 1_000_000 * D_ * 4 * 1.02 and used_default >= 1_000_000 * D_ * 5 * 0.98
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_randomised_differential_against_the_exact_kernel(mdr, seed):
     """Random sizes, query counts and data families (gaussian, uniform, sparse, low-rank + noise, clustered with exact duplicates and
