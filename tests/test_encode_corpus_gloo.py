@@ -118,7 +118,20 @@ def test_length_bucket_collate_keeps_row_indices():
     from multihop_dense_retrieval_amd.encode_corpus import LengthBucketCollate
     samples = [(10 + i, {"input_ids": torch.arange(L)[None, :], "attention_mask": torch.ones((1, L), dtype=torch.int64)})
                for i, L in enumerate([5, 2, 9, 2, 7, 1])]
+    from multihop_dense_retrieval_amd.data import em_collate
+    from multihop_dense_retrieval_amd.encode_corpus import expand_compact
     out = LengthBucketCollate(4)(samples)
     assert [r.tolist() for r, _ in out] == [[15, 11, 13, 10], [14, 12]]  # sorted by (length, row), cut into batches of 4
-    assert out[0][1]["input_ids"].shape == (4, 5) and out[1][1]["input_ids"].shape == (2, 9)
-    assert out[0][1]["input_mask"].sum(1).tolist() == [1, 2, 2, 5]
+    # workers hand over compact batches (one int32 token vector + lengths); expand_compact rebuilds em_collate's dict bit for bit
+    assert all("_compact_flat" in b and b["_compact_flat"].dtype == torch.int32 for _, b in out)
+    by_row = {r: s for r, s in samples}
+    for rows, b in out:
+        got = expand_compact(b, lambda x: x)
+        want = em_collate([by_row[r] for r in rows.tolist()])
+        assert sorted(got) == sorted(want) and all(torch.equal(got[k], want[k]) and got[k].dtype == want[k].dtype for k in want)
+    b0 = expand_compact(out[0][1], lambda x: x)
+    assert b0["input_ids"].shape == (4, 5) and expand_compact(out[1][1], lambda x: x)["input_ids"].shape == (2, 9)
+    assert b0["input_mask"].sum(1).tolist() == [1, 2, 2, 5]
+    # a mask that is not all ones (or token_type_ids) keeps the padded form
+    odd = [(0, {"input_ids": torch.arange(3)[None, :], "attention_mask": torch.tensor([[1, 1, 0]])})]
+    assert "input_ids" in LengthBucketCollate(4)(odd)[0][1]
