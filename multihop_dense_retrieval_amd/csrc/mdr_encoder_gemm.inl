@@ -1,4 +1,5 @@
 // csrc/mdr_encoder_gemm.inl -- the fp16 MFMA GEMMs: one-tile-per-block kernel (small / medium M), persistent 256x128 kernel, persistent 256x256 kernel, erf-GELU epilogue.
+// (The four-wave 256x256 kernel with the generated K-loop lives in mdr_encoder_gemm_quad.inl and shares this file's epilogue helpers.)
 // Included by mdr_encoder.hip inside namespace mdr::{anonymous}.
 // ---- GEMM: C[M,N] = A[M,K] (fp16, row-major) x W[N,K]^T (fp16, row-major) -----------------------------
 // Block tile BM x BN x 64 computed by WGM x WGN waves (wave tile = (BM/WGM) x (BN/WGN) as 16x16 MFMA tiles),

@@ -79,6 +79,7 @@ gemm_quad_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __rest
     using C = GemmB2;
     extern __shared__ __attribute__((aligned(16))) char lds[];  // the only LDS of the kernel: starts at address 0 (the asm XORs slot addresses)
     float* lds_bias = (float*)(lds + C::LDS_BYTES);
+    if ((unsigned)(size_t)lds != 0u) __builtin_trap();  // the generated K-loop XORs slot addresses: the ring has to start at LDS address 0
     const int M = M_dev ? min(*M_dev, M_cap) : M_cap;
     const int ntn = N / 256, ntm = (M + 255) / 256;
     const long long T_all = (long long)ntm * ntn;  // tile order and XCD ownership: see gemm_persist_kernel
