@@ -84,3 +84,31 @@ for name, f in (("enc", enc), ("search", search), ("both", both), ("both_late", 
     res[name] = round(timeit(f), 3)
 print("overlap probe (ms per iteration):", res)
 print("sum enc + search = %.3f; gain if pipelined one stage deeper = %.3f ms per step" % (res["enc"] + res["search"], res["enc"] + res["search"] - min(res["both"], res["both_late"])))
+
+# ---- hop-1 questions of G future batches encoded as ONE forward every G-th step (offline evaluation knows all questions up front)
+for G in (1, 2, 4, 8):
+    ids_g, mask_g = pipe.q_ids.repeat(G, 1), pipe.q_mask.repeat(G, 1)
+    pipe.encoder.encode_q(ids_g, mask_g, None, lane=1)
+    pipe.encoder.encode_q(ids_g, mask_g, None, lane=1)
+    torch.cuda.synchronize()
+    state = {"i": 0}
+
+    def enc_grouped():
+        do = state["i"] % G == 0
+        state["i"] += 1
+        start = torch.cuda.Event(); start.record()
+        if do:
+            side.wait_event(start)
+            with torch.cuda.stream(side):
+                pipe.encoder.encode_q(ids_g, mask_g, None, lane=1)
+                done = torch.cuda.Event(); done.record()
+        pipe._encode(ids2, mask2)
+        if do:
+            main.wait_event(done)
+
+    def alone():
+        pipe.encoder.encode_q(ids_g, mask_g, None, lane=1)
+
+    t_alone = timeit(alone, 10)
+    t = timeit(enc_grouped, 8 * max(G, 3))
+    print(f"hop-1 group of {G} batches ({100 * G} questions): forward alone {t_alone:.3f} ms = {t_alone / G:.3f} per batch; encoder stage per step {t:.3f} ms")
