@@ -168,7 +168,8 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
         // the stores made the K = 768 GEMMs 25-30 % faster, deferring them did not): cost = rounds x (tile inputs + outputs).
         // the 256x256 kernels store through a buffer descriptor with 32-bit byte offsets: outputs of 4 GiB and more go to the 256x128 kernel
         const bool out32 = (unsigned long long)M_cap * (unsigned long long)ldo * (E == EPI_BIAS_F32 ? 4ull : 2ull) < (1ull << 32);
-        if (sel == 7 && out32 && N % 256 == 0 && K % 128 == 0 && K >= 256) return launch_gemm_quad<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
+        const bool a32 = (unsigned long long)M_cap * (unsigned long long)lda * 2ull < (1ull << 32);  // the four-wave kernel also LOADS A through a descriptor
+        if (sel == 7 && out32 && a32 && N % 256 == 0 && K % 128 == 0 && K >= 256) return launch_gemm_quad<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
         if ((sel == 6 || sel == 0) && N % 256 == 0 && out32) {
             const double osz = (E == EPI_BIAS_F32) ? 4.0 : 2.0;
             const double c_big = persistent_rounds(M_est, 256, N, 256, num_cus / 8) * ((256.0 + 256.0) * K * 2 + 256.0 * 256.0 * osz);
@@ -178,7 +179,7 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
                 // wave per SIMD has nobody to hide its latencies). Measured at 20.3 k rows: FFN2 77 vs 83-86 us, out-projection 30-33 vs 31-37,
                 // but QKV 84-89 vs 70-72 and FFN1 113-123 vs 106-117 (three / four tiles per workgroup, K = 768): taken where the K-loop dominates.
                 const int rounds = persistent_rounds(M_est, 256, N, 256, num_cus / 8);
-                if (sel == 0 && K % 128 == 0 && K >= 256 && (rounds == 1 || K >= 2048))
+                if (sel == 0 && a32 && K % 128 == 0 && K >= 256 && (rounds == 1 || K >= 2048))
                     return launch_gemm_quad<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
                 return launch_gemm_big<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
             }
