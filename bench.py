@@ -104,8 +104,16 @@ def parse():
     ap.add_argument("--aniso-m", type=float, nargs="*", default=[20.0, 200.0], help="norms m of the common component of the anisotropic sub-result")
     ap.add_argument("--dump-ids", default=None, help="rank 0 writes the last step's hop-1 / hop-2 ids and scores to this .npz (tests)")
     ap.add_argument("--no-strong", action="store_true", help="N>1, weak scaling: do not append the strong-scaling sub-result")
-    ap.add_argument("--mode", choices=["retrieval", "encode-corpus"], default="retrieval",
-                    help="encode-corpus: throughput of the corpus encoder (scripts/encode_corpus.py path) on a synthetic pre-tokenised corpus")
+    ap.add_argument("--mode", choices=["retrieval", "encode-corpus", "cli"], default="retrieval",
+                    help="encode-corpus: throughput of the corpus encoder (scripts/encode_corpus.py path) on a synthetic pre-tokenised corpus; "
+                         "cli: queries/s of the drop-in CLI itself (scripts/eval/eval_mhop_retrieval.py main()) on synthetic assets of the headline's size")
+    ap.add_argument("--questions", type=int, default=7405, help="--mode cli: questions in the synthetic qas file (HotpotQA dev has 7405)")
+    ap.add_argument("--cli-dir", default=None, help="--mode cli: where the synthetic assets go (default: /dev/shm when it has room, else /tmp); removed afterwards")
+    ap.add_argument("--cli-workers", type=int, default=10, help="--mode cli: the CLI's --num-workers (tokenizer worker processes; the reference's default is 10)")
+    ap.add_argument("--cli-legs", default="default,device", help="--mode cli: which flag sets to run: default = the reference's flags, device = --hop2-on-device --pipeline-batches")
+    ap.add_argument("--pool", type=int, default=16,
+                    help="DIFFERENT question batches the timed steps cycle through (different lengths -> different hop-1 answers -> 19-22 k hop-2 tokens per batch "
+                         "on the synthetic corpus); 1 = every step re-runs one batch (rounds 1-3)")
     ap.add_argument("--passages", type=int, default=100_000, help="--mode encode-corpus: synthetic passages")
     ap.add_argument("--predict-batch-size", type=int, default=1000, help="--mode encode-corpus: the README's --predict_batch_size")
     return ap.parse_args()
@@ -449,10 +457,109 @@ def encode_corpus_mode(args):
                       "note": "value = device-resident token batches -> forward -> D2H of the embeddings -> host matrix (predict()'s per-batch work)"}), flush=True)
 
 
+def cli_mode(args):
+    """queries/s of the DROP-IN CLI: synthetic assets of the headline's size on disk (scripts/cli_bench_assets.py: a 5 M x 768
+    fp32 .npy, a 5 M-passage corpus store + token arena, a roberta-base-geometry checkpoint, a real HF byte-level BPE tokenizer over the tiny
+    vocabulary, 7 405 questions), then eval_mhop_retrieval.main() with (a) the reference's flags and (b) --hop2-on-device --pipeline-batches. The
+    timed region is the CLI's own batch loop ("Encoding questions and searching": tokenisation, both encoder passes, both searches, path ranking,
+    metrics, output records; between a device sync on either side), not model / index / corpus loading. The device-resident loop of the default
+    mode is timed first in the same process, so the ratio is a same-box number."""
+    import shutil
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import cli_bench_assets
+    from multihop_dense_retrieval_amd import eval_mhop_retrieval, mhop
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    N, d, B = args.rows, args.dim, args.batch
+    need = N * (d * 4 + 180 * 4 + 180 * 4 + 64) + (1 << 30)
+    out_dir = args.cli_dir
+    if out_dir is None:
+        shm_ok = os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and shutil.disk_usage("/dev/shm").free > 1.3 * need
+        out_dir = "/dev/shm/mdr_cli_bench" if shm_ok else "/tmp/mdr_cli_bench"
+    result = {"metric": "queries/sec (drop-in CLI eval_mhop_retrieval.main, 2-hop, beam-size x topk) over 5Mx768 index", "unit": "queries/s", "n_gpus": world,
+              "higher_is_better": True, "data": "synthetic", "dtype": "f32 (index stored as fp16 hi/lo pairs, fp32 accumulate); encoder f16 MFMA / f32 accumulate",
+              "config": {"workload": f"scripts/eval/eval_mhop_retrieval.py on synthetic {N}x{d} fp32 index.npy + {N}-passage corpus store, {args.questions} questions, "
+                                     f"batch {B}, beam={args.beam} topk={args.topk}, RoBERTa-base geometry (random init), tokenizer = HF byte-level BPE over the tiny vocabulary",
+                         "rows": N, "questions": args.questions, "batch": B, "beam": args.beam, "topk": args.topk, "num_workers": args.cli_workers,
+                         "host_threads": len(os.sched_getaffinity(0)), "assets_dir": out_dir}}
+    # (1) the device-resident loop of the default mode on this box, this process: the number the CLI is compared with
+    if world == 1 and not args.no_sequential:
+        sidx, local, lo, hi, GB, planted, rows_sum = build_pipeline(args, 1, 0, device, None, False)
+        pipe = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len, max_q_sp_len=args.max_q_sp_len,
+                                    use_encoder=True, planted_rows=rows_sum, pipelined=True, pool=args.pool)
+        _, el = timed_steps(pipe, args, 1, device, None)
+        result["device_loop"] = {"value": round(B * args.steps / el, 2), "unit": "queries/s", "ms_per_step": round(el / args.steps * 1e3, 4),
+                                 "note": "bench.py default mode (device-resident synthetic loop, software-pipelined), same box, same process"}
+        del pipe, sidx, local
+        torch.cuda.empty_cache()
+    # (2) the assets
+    ready = os.path.join(out_dir, "READY")
+    if rank == 0:
+        shutil.rmtree(out_dir, ignore_errors=True)
+        assets = cli_bench_assets.build(out_dir, N, args.questions, device, log=lambda m: print(m, file=sys.stderr, flush=True))
+        json.dump(assets, open(ready, "w"))
+    else:
+        while not os.path.exists(ready):
+            time.sleep(0.5)
+        assets = json.load(open(ready))
+    result["config"]["assets_build_s"] = assets["build_seconds"]
+    torch.cuda.empty_cache()
+    legs = {"default": [], "device": ["--hop2-on-device", "--pipeline-batches"]}
+    base = [assets["raw_data"], assets["indexpath"], assets["corpus_dict"], assets["model_path"], "--batch-size", str(B), "--beam-size", str(args.beam),
+            "--topk", str(args.topk), "--shared-encoder", "--model-name", assets["model_name"], "--gpu", "--max-q-len", str(args.max_q_len),
+            "--max-q-sp-len", str(args.max_q_sp_len), "--num-workers", str(args.cli_workers)]
+    outs = {}
+    try:
+        for name in [x for x in args.cli_legs.split(",") if x]:
+            save = os.path.join(out_dir, f"paths_{name}.jsonl")
+            t0 = time.perf_counter()
+            metrics, recs = eval_mhop_retrieval.main(base + ["--save-path", save] + legs[name])
+            wall = time.perf_counter() - t0
+            run = dict(eval_mhop_retrieval.LAST_RUN)
+            outs[name] = save
+            if rank == 0:
+                done = run["stats"].get("batch_done_t", [])
+                steady = None
+                if len(done) > 12:  # the first batches carry the hipGraph captures: rate over the rest
+                    steady = round((len(done) - 1 - 8) * B / (done[-1] - done[8]), 2)
+                result[f"cli_{name}"] = {"flags": " ".join(legs[name]) or "(the reference's flags)", "value": round(run["questions"] / run["loop_seconds"], 2),
+                                        "unit": "queries/s", "loop_seconds": round(run["loop_seconds"], 4), "ms_per_batch": round(run["loop_seconds"] / max(1, -(-run["questions"] // B)) * 1e3, 4),
+                                        "steady_state_queries_per_s": steady, "whole_main_seconds": round(wall, 2), "records": len(recs), "graph_captures": run["graph_captures"],
+                                        "graph_replays": run["graph_replays"], "encoder_forward_calls": run["encoder_forward_calls"],
+                                        "stats": {k: v for k, v in run["stats"].items() if k != "batch_done_t"}}
+            torch.cuda.empty_cache()
+        if rank == 0 and len(outs) == 2:
+            a, b = (open(p).read() for p in outs.values())
+            result["legs_jsonl_identical"] = a == b
+    finally:
+        if world > 1:
+            torch.distributed.barrier()
+        if rank == 0:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    if rank == 0:
+        best = max((v for k, v in result.items() if k.startswith("cli_")), key=lambda v: v["value"], default=None)
+        if best is not None:
+            result["value"] = best["value"]
+            result["best_leg"] = best["flags"]
+            if "device_loop" in result:
+                result["cli_over_device_loop"] = round(best["value"] / result["device_loop"]["value"], 3)
+        print(json.dumps(result), flush=True)
+    if world > 1 and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.mode == "encode-corpus":
         return encode_corpus_mode(args)
+    if args.mode == "cli":
+        return cli_mode(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -484,7 +591,7 @@ def main():
     pipe = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device,
                                 max_q_len=args.max_q_len, max_q_sp_len=args.max_q_sp_len,
                                 use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank, world=world, weak=weak,
-                                pipelined=not args.sequential)
+                                pipelined=not args.sequential, pool=args.pool)
     out, elapsed = timed_steps(pipe, args, world, device, dist)
 
     # self-checks, outside the timed region: structural properties + exactness against a brute-force pass over ALL rows
@@ -526,10 +633,16 @@ def main():
     }
     if pipe.use_encoder:
         # ---- second roofline entry: the encoder (MFMA-bound), the larger share of the step --------------------------------
-        q_lens = pipe.q_len.cpu().numpy()
-        sp_lens = out["mask2"].sum(1).cpu().numpy()
-        e1, p1 = encoder_flops(q_lens, args.max_q_len)
-        e2, p2 = encoder_flops(sp_lens, args.max_q_sp_len)
+        # executed FLOPs averaged over the timed steps (the pool's batches differ): hop 1 from each step's question lengths, hop 2 from the lengths its
+        # assembly produced
+        log = list(pipe.step_log)
+        f1 = [encoder_flops(pipe.batches[ent]["q_len"].cpu().numpy(), args.max_q_len) for ent, _ in log]
+        f2 = [encoder_flops(lens.cpu().numpy(), args.max_q_sp_len) for _, lens in log]
+        e1, p1 = float(np.mean([f[0] for f in f1])), float(np.mean([f[1] for f in f1]))
+        e2, p2 = float(np.mean([f[0] for f in f2])), float(np.mean([f[1] for f in f2]))
+        q_lens = np.concatenate([pipe.batches[ent]["q_len"].cpu().numpy() for ent, _ in log]) / 1.0
+        sp_lens = np.concatenate([lens.cpu().numpy() for _, lens in log]) / 1.0
+        nlog = max(1, len(log))
         enc_ms = stage["hop1_encode"] + stage["hop2_encode"]  # pipelined: hop2_encode = wall time of the hop-2 forward AND the next batch's hop-1 forward beside it (hop1_encode is 0)
         if world > 1 and not weak:  # strong scaling: each rank encodes 1/world of the rows, the rest of the stage is the all-gather
             e1, p1, e2, p2 = e1 / world, p1 / world, e2 / world, p2 / world
@@ -539,11 +652,11 @@ def main():
             "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
             "executed_flop_per_step": round(e1 + e2), "padded_equivalent_flop_per_step": round(p1 + p2),
             "padded_equivalent_TFLOPs": round((p1 + p2) / (enc_ms * 1e-3) / 1e12, 1),
-            "hop1": {"ms": stage["hop1_encode"], "tokens": int(q_lens.sum()),
+            "hop1": {"ms": stage["hop1_encode"], "tokens": int(q_lens.sum() / nlog),
                      "TFLOPs": round(e1 / (stage["hop1_encode"] * 1e-3) / 1e12, 1) if stage["hop1_encode"] > 0 else None},
-            "hop2": {"ms": stage["hop2_encode"], "tokens": int(sp_lens.sum()),
+            "hop2": {"ms": stage["hop2_encode"], "tokens": int(sp_lens.sum() / nlog),
                      "TFLOPs": round(e2 / (stage["hop2_encode"] * 1e-3) / 1e12, 1),
-                     **({"side_stream_hop1": {"tokens": int(q_lens.sum()), "flop": round(e1),
+                     **({"side_stream_hop1": {"tokens": int(q_lens.sum() / nlog), "flop": round(e1),
                                               "note": "the next batch's hop-1 forward runs CONCURRENTLY on a second stream inside this stage's time; "
                                                       "`achieved` above counts both forwards' FLOPs over it, this entry's TFLOPs only the hop-2 forward's"}}
                         if pipe.pipelined else {})},
@@ -553,6 +666,25 @@ def main():
                                    "on RANDOM operands on this pool (2.35-2.41 on zeros): the chip clocks to its power limit (~1.7 GHz under a full matrix pipe); `frac` above is "
                                    "against the nominal 2.5 PFLOP/s",
             "note": "executed FLOPs (masked tokens dropped, last layer CLS-only) / HIP-event stage time on the launch stream; peak = dense fp16 MFMA"}
+    if pipe.use_encoder:
+        # ---- the step time over the pool's DIFFERENT batches: min / mean / max, per 1 k hop-2 tokens, and which 256-row tile counts occurred
+        ps = pipe.per_step()
+        if ps:
+            ms = np.array([p[0] for p in ps])
+            tk = np.array([p[2] for p in ps], np.float64)
+            tiles = {}
+            for t in tk:
+                key = str(int(-(-t // 256)))
+                tiles[key] = tiles.get(key, 0) + 1
+            per_k = ms / (tk / 1e3)
+            result["per_step"] = {"pool": pipe.pool, "steps": len(ps), "ms": {"min": round(float(ms.min()), 4), "mean": round(float(ms.mean()), 4), "max": round(float(ms.max()), 4)},
+                                  "max_over_min_ms": round(float(ms.max() / ms.min()), 4),
+                                  "hop2_tokens": {"min": int(tk.min()), "mean": int(tk.mean()), "max": int(tk.max())},
+                                  "ms_per_1k_hop2_tokens": {"min": round(float(per_k.min()), 5), "mean": round(float(per_k.mean()), 5), "max": round(float(per_k.max()), 5)},
+                                  "max_over_min_ms_per_token": round(float(per_k.max() / per_k.min()), 4),
+                                  "row_tiles_of_256_histogram": dict(sorted(tiles.items())),
+                                  "note": "one entry per timed step but the last (a step = first event of the step to the first event of the next, main stream); the work of a step "
+                                          "scales with its hop-2 tokens, so the tile-round steps of the persistent GEMMs show in ms_per_1k_hop2_tokens"}
     if hasattr(local, "telemetry") and calls_nq(pipe):  # which screening tier decided the LAST search of the timed region (test hook; outside it)
         t = local.telemetry(calls_nq(pipe), args.beam)
         result["mips_tiers"] = {"int8_tier_ran": t["i8_tier"], "int8_tier_handed_over": t["i8_overflow"], "exact_fallback_ran": bool(t["fallback"]),
@@ -566,7 +698,7 @@ def main():
         mhop.SyntheticTwoHop._defer_encoder = True  # share the encoder and the arena of the main pipeline
         pipe_q = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
                                       max_q_sp_len=args.max_q_sp_len, use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank,
-                                      world=world, weak=weak, pipelined=False)
+                                      world=world, weak=weak, pipelined=False, pool=args.pool)
         mhop.SyntheticTwoHop._defer_encoder = False
         if pipe.use_encoder:
             pipe_q.encoder, pipe_q.arena = pipe.encoder, pipe.arena  # same weights, same token arena
@@ -575,31 +707,40 @@ def main():
                                 "stage_ms": pipe_q.stage_ms(), "mips_roofline": mips_roofline(pipe_q, local, args, d)}
         del pipe_q
 
-    if pipe.pipelined and pipe.use_encoder and world == 1 and not args.no_sequential and not getattr(pipe.encoder, "residual_fp32", False):
-        # the same job with the apex-O1-faithful fp32 residual stream (a numerics MODE of the encoder, off by default: DESIGN.md section 4): what the
-        # headline would be with it, and how far the two modes' embeddings are apart -- a sub-result of the same line
+    if pipe.pipelined and pipe.use_encoder and world == 1 and not args.no_sequential:
+        # the same job in the encoder's OTHER residual-stream numerics modes (mdr_encoder_config.residual_fp32; the headline runs the default, an
+        # apex-O1-faithful one: DESIGN.md section 4): what each costs and how far its embeddings are from the default's -- sub-results of the same line
         from multihop_dense_retrieval_amd.retriever import RobertaRetriever
-        prev = os.environ.get("MDR_RESIDUAL_FP32")
-        os.environ["MDR_RESIDUAL_FP32"] = "1"  # read when the encoder object is made (the device handle is created with the mode)
-        try:
-            enc32 = RobertaRetriever.random_init(device=device, seed=3)
-        finally:
-            if prev is None:
-                del os.environ["MDR_RESIDUAL_FP32"]
-            else:
-                os.environ["MDR_RESIDUAL_FP32"] = prev
-        assert enc32.residual_fp32
-        mhop.SyntheticTwoHop._defer_encoder = True
-        pipe_r = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
-                                      max_q_sp_len=args.max_q_sp_len, use_encoder=True, planted_rows=rows_sum, rank=rank, world=world, weak=weak, pipelined=True)
-        mhop.SyntheticTwoHop._defer_encoder = False
-        pipe_r.encoder, pipe_r.arena = enc32, pipe.arena
-        out_r, el_r = timed_steps(pipe_r, args, world, device, dist)
-        result["residual_fp32"] = {"value": round(GB * args.steps / el_r, 2), "unit": "queries/s", "ms_per_step": round(el_r / args.steps * 1e3, 4),
-                                   "hop1_embedding_max_abs_diff_vs_default": round(float((out_r["q"] - out["q"]).abs().max()), 6),
-                                   "hop1_ids_equal_to_default": bool((out_r["I"] == out["I"]).all()),
-                                   "note": "encoder.residual_fp32 = 1: LayerNorm outputs stay fp32 for the residual adds (what apex O1 does); the default rounds them to fp16"}
-        del pipe_r, enc32
+        names = {0: "fp16 residual copy (one more rounding per LayerNorm than apex O1; NOT O1-faithful)",
+                 1: "fp32 residual stream, fp32 Linear sums (O1-faithful, more accurate than apex O1)",
+                 2: "fp32 residual stream, out-projection / FFN2 outputs rounded to fp16 (apex O1's own dataflow)"}
+        result["numerics_mode"] = {"residual_fp32": int(pipe.encoder.residual_fp32), "meaning": names[int(pipe.encoder.residual_fp32)]}
+        result["numerics_modes"] = {}
+        for mode in (0, 1, 2):
+            if mode == int(pipe.encoder.residual_fp32):
+                continue
+            prev = os.environ.get("MDR_RESIDUAL_FP32")
+            os.environ["MDR_RESIDUAL_FP32"] = str(mode)  # read when the encoder object is made (the device handle is created with the mode)
+            try:
+                enc_m = RobertaRetriever.random_init(device=device, seed=3)
+            finally:
+                if prev is None:
+                    del os.environ["MDR_RESIDUAL_FP32"]
+                else:
+                    os.environ["MDR_RESIDUAL_FP32"] = prev
+            assert int(enc_m.residual_fp32) == mode
+            mhop.SyntheticTwoHop._defer_encoder = True
+            pipe_r = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
+                                          max_q_sp_len=args.max_q_sp_len, use_encoder=True, planted_rows=rows_sum, rank=rank, world=world, weak=weak, pipelined=True,
+                                          pool=args.pool)
+            mhop.SyntheticTwoHop._defer_encoder = False
+            pipe_r.encoder, pipe_r.arena = enc_m, pipe.arena
+            out_r, el_r = timed_steps(pipe_r, args, world, device, dist)
+            result["numerics_modes"][f"residual_fp32={mode}"] = {
+                "value": round(GB * args.steps / el_r, 2), "unit": "queries/s", "ms_per_step": round(el_r / args.steps * 1e3, 4), "meaning": names[mode],
+                "hop1_embedding_max_abs_diff_vs_default": round(float((out_r["q"] - out["q"]).abs().max()), 6) if out_r["q"].shape == out["q"].shape else None,
+                "hop1_ids_equal_to_default": bool((out_r["I"] == out["I"]).all()) if out_r["I"].shape == out["I"].shape else None}
+            del pipe_r, enc_m
 
     if world > 1 and weak and not args.no_strong:
         # The same job with ONE 100-question batch shared by all ranks (the reference's fixed --batch-size): a sub-result of
@@ -608,7 +749,7 @@ def main():
         pipe_s = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
                                       max_q_sp_len=args.max_q_sp_len, use_encoder=not args.no_encoder,
                                       planted_rows=torch.zeros((B, d), device=device), rank=rank, world=world, weak=False,
-                                      pipelined=pipe.pipelined)
+                                      pipelined=pipe.pipelined, pool=args.pool)
         mhop.SyntheticTwoHop._defer_encoder = False
         if pipe.use_encoder:
             pipe_s.encoder, pipe_s.arena = pipe.encoder, pipe.arena

@@ -122,6 +122,14 @@ const char* mdr_index_last_kernel(const mdr_index* h);
 int mdr_topk_merge(const float* D_parts_dev, const int64_t* I_parts_dev, int nparts, int nq, int k,
                    float* D_dev, int64_t* I_dev, void* stream);
 
+/* The same merge over PACKED per-rank blocks, so that the exchange needs no glue kernels: a rank's search writes its (D, I) straight
+ * into one block of mdr_topk_packed_bytes(nq, k) bytes -- scores f32 [nq, k] at offset 0, ids i64 [nq, k] at
+ * mdr_topk_packed_ids_offset(nq, k) -- ONE all-gather of that block over the ranks (RCCL over xGMI) delivers
+ * packed_parts_dev = nparts consecutive blocks, and this call merges them (8-byte aligned; order rule as above). */
+size_t mdr_topk_packed_bytes(int nq, int k);
+size_t mdr_topk_packed_ids_offset(int nq, int k);
+int mdr_topk_merge_packed(const void* packed_parts_dev, int nparts, int nq, int k, float* D_dev, int64_t* I_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * RoBERTa-base encoder forward + CLS projection  ==
  *   RobertaRetriever.encode_q / encode_seq   /root/reference/mdr/retrieval/models/mhop_retriever.py:23-26,40-41
@@ -138,7 +146,10 @@ typedef struct mdr_encoder_config {
     /* 1: LayerNorm outputs are kept in fp32 for the residual adds, only the copy that feeds the next Linear is rounded to
      *    fp16 -- the apex-O1 regime the reference runs under (eval_mhop_retrieval.py:88-89: LayerNorm is an fp32 op, the
      *    residual add promotes to fp32). 0: the residual stream is the fp16 copy (less HBM traffic, one more rounding per
-     *    LayerNorm). Results differ inside fp16-operand noise; DESIGN.md §4 has the measured cost and error of both. */
+     *    LayerNorm). 2: fp32 residual stream as in 1, and the out-projection / FFN2 outputs are rounded to fp16 BEFORE the residual
+     *    add -- literally what apex O1 computes there (F.linear returns fp16; `hidden + input_tensor` promotes to fp32) and half the
+     *    bytes in and out of those GEMM epilogues. Results differ inside fp16-operand noise; DESIGN.md §4 has the measured cost and
+     *    error of each. */
     int residual_fp32;
 } mdr_encoder_config;
 

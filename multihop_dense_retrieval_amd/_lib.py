@@ -51,6 +51,9 @@ _SIGNATURES = {
     "mdr_index_set_variant": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "mdr_index_last_kernel": (_c.c_char_p, [_c.c_void_p]),
     "mdr_topk_merge": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "mdr_topk_packed_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
+    "mdr_topk_packed_ids_offset": (_c.c_size_t, [_c.c_int, _c.c_int]),
+    "mdr_topk_merge_packed": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "mdr_assemble_hop2": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                      _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "mdr_encoder_create": (_c.c_int, [_c.POINTER(EncoderConfig), _c.POINTER(Tensor), _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,

@@ -11,6 +11,22 @@ import torch
 from . import _lib
 
 
+def arena_tag(tokenizer, roberta, max_tokens):
+    """What a cached arena is valid for: the tokenisation RULE (2.11's prefix space, data.PREFIX_SPACE_2_11), the tokenizer class and
+    vocabulary, the empty-text rule and the token cap. A cache written under another tag is rebuilt, never silently reused (ADVICE r3:
+    an arena tokenised without the prefix space would disagree with the host path at the first BPE token of every passage)."""
+    import hashlib
+    import json
+
+    from .data import PREFIX_SPACE_2_11, is_roberta_family
+    try:
+        vocab = hashlib.sha256(json.dumps(sorted(tokenizer.get_vocab().items())).encode()).hexdigest()[:16]
+    except Exception:
+        vocab = "unknown"
+    return (f"arena-v2|prefix_space_2_11={int(PREFIX_SPACE_2_11 and is_roberta_family(tokenizer))}|tokenizer={tokenizer.__class__.__name__}|vocab={vocab}"
+            f"|empty_text_to_title={int(bool(roberta))}|max_tokens={max_tokens}")
+
+
 class TokenArena:
     def __init__(self, tokens, offsets, empty=None, bos_id=0, eos_id=2, pad_id=1):
         self.tokens = tokens.to(dtype=torch.int32).contiguous()
@@ -58,13 +74,17 @@ class TokenArena:
         tokens = torch.randint(3, vocab, (total,), generator=g, device=device, dtype=torch.int32)
         return cls(tokens, offsets, None)
 
-    def save(self, path):
+    def save(self, path, tag=""):
+        """np.savez appends ".npz" unless the name ends with it; `tag` (arena_tag) records what the tokens are valid for."""
         np.savez(path, tokens=self.tokens.cpu().numpy(), offsets=self.offsets.cpu().numpy(),
-                 empty=(np.zeros(0, np.uint8) if self.empty is None else self.empty.cpu().numpy()))
+                 empty=(np.zeros(0, np.uint8) if self.empty is None else self.empty.cpu().numpy()), tag=np.array(str(tag)))
 
     @classmethod
-    def load(cls, path):
+    def load(cls, path, expect_tag=None):
+        """expect_tag: return None (caller rebuilds) when the file carries no tag or a different one."""
         z = np.load(path)
+        if expect_tag is not None and ("tag" not in z.files or str(z["tag"]) != str(expect_tag)):
+            return None
         return cls(torch.from_numpy(z["tokens"]), torch.from_numpy(z["offsets"]), torch.from_numpy(z["empty"]) if z["empty"].size else None)
 
     # -- the device op -------------------------------------------------------------------------------------

@@ -243,6 +243,7 @@ int mdr_encoder_create(const mdr_encoder_config* cfg, const mdr_tensor* tensors,
     MDR_REQUIRE(cfg->heads > 0 && cfg->hidden == cfg->heads * 64, "head dim must be 64 (hidden=%d heads=%d)", cfg->hidden, cfg->heads);
     MDR_REQUIRE(cfg->ffn > 0 && cfg->ffn % 128 == 0, "ffn=%d must be a multiple of 128", cfg->ffn);
     MDR_REQUIRE(cfg->layers > 0 && cfg->vocab > 0 && cfg->max_pos > 2, "bad geometry");
+    MDR_REQUIRE(cfg->residual_fp32 >= 0 && cfg->residual_fp32 <= 2, "residual_fp32=%d must be 0, 1 or 2", cfg->residual_fp32);
     int ndev = 0;
     MDR_HIP_TRY(hipGetDeviceCount(&ndev));
     MDR_REQUIRE(device >= 0 && device < ndev, "device %d out of range", device);
@@ -430,6 +431,9 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
     // that feeds the next Linear is rounded to fp16. In that mode no GEMM epilogue adds the (fp16) residual: every
     // LayerNorm call takes it from w.h32 and refreshes w.h32 in place.
     const bool r32 = c.residual_fp32 != 0;
+    const bool p16 = c.residual_fp32 == 2;  // out-projection / FFN2 outputs rounded to fp16 before the residual add (what apex O1's F.linear returns)
+    _Float16* pre16 = (_Float16*)w.pre;     // (the fp16 sums live in the fp32 buffer's memory)
+    _Float16* clspre16 = (_Float16*)w.clspre;
     hipLaunchKernelGGL(embed_ln_kernel, dim3((Tcap + 3) / 4), dim3(256), 0, st, ids, (const int*)w.tok_src, (const int*)w.tok_pid, (const int*)w.total,
                        (const float*)h->word, (const float*)h->pos, (const float*)h->type0, (const float*)h->emb_g, (const float*)h->emb_b, H, c.vocab,
                        c.max_pos, c.ln_eps, w.h16, w.h32);
@@ -438,8 +442,12 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
     // y = LayerNorm(gemm_out + residual) for `rows` rows: one place that knows where the residual comes from
     auto post_ln = [&](const float* pre, bool res_in_gemm, const _Float16* res16, float* res32, int rows_cap, const int* rows_dev, const float* g_,
                        const float* b_, _Float16* out16, float* out32) {
-        hipLaunchKernelGGL(layernorm_kernel, dim3((rows_cap + 3) / 4), dim3(256), 0, st, pre, (const _Float16*)(r32 || res_in_gemm ? nullptr : res16),
-                           (const float*)(r32 ? res32 : nullptr), rows_cap, rows_dev, H, g_, b_, c.ln_eps, out16, (float*)(r32 ? out32 : nullptr));
+        if (p16)
+            hipLaunchKernelGGL(layernorm_kernel<_Float16>, dim3((rows_cap + 3) / 4), dim3(256), 0, st, (const _Float16*)pre, (const _Float16*)nullptr,
+                               (const float*)res32, rows_cap, rows_dev, H, g_, b_, c.ln_eps, out16, out32);
+        else
+            hipLaunchKernelGGL(layernorm_kernel<float>, dim3((rows_cap + 3) / 4), dim3(256), 0, st, pre, (const _Float16*)(r32 || res_in_gemm ? nullptr : res16),
+                               (const float*)(r32 ? res32 : nullptr), rows_cap, rows_dev, H, g_, b_, c.ln_eps, out16, (float*)(r32 ? out32 : nullptr));
     };
     for (int i = 0; i < c.layers; ++i) {
         const mdr_encoder::Layer& Ly = h->layers[i];
@@ -452,13 +460,15 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
             hipLaunchKernelGGL(attention_cls_kernel, dim3(c.heads, B), dim3(64), 0, st, (const _Float16*)w.qkv, (const int*)w.cu, H, w.ctx);
             MDR_HIP_TRY(hipGetLastError());
             bool res_in = true;
-            if (r32) rc = launch_gemm<EPI_BIAS_F32>(w.ctx, H, Ly.wo, Ly.bo, B, nullptr, H, H, w.clspre, H, nullptr, 0, B, ncu, st);
+            if (p16) rc = launch_gemm<EPI_BIAS_F16>(w.ctx, H, Ly.wo, Ly.bo, B, nullptr, H, H, clspre16, H, nullptr, 0, B, ncu, st);
+            else if (r32) rc = launch_gemm<EPI_BIAS_F32>(w.ctx, H, Ly.wo, Ly.bo, B, nullptr, H, H, w.clspre, H, nullptr, 0, B, ncu, st);
             else rc = launch_gemm<EPI_BIAS_RES_F32>(w.ctx, H, Ly.wo, Ly.bo, B, nullptr, H, H, w.clspre, H, w.cls16, H, B, ncu, st, &res_in);
             if (rc) return rc;
             post_ln(w.clspre, res_in, w.cls16, w.cls32, B, nullptr, Ly.ln1_g, Ly.ln1_b, w.cls16, w.cls32);
             rc = launch_gemm<EPI_BIAS_GELU_F16>(w.cls16, H, Ly.w1, Ly.b1, B, nullptr, F, H, w.ffn, F, nullptr, 0, B, ncu, st);
             if (rc) return rc;
-            if (r32) rc = launch_gemm<EPI_BIAS_F32>(w.ffn, F, Ly.w2, Ly.b2, B, nullptr, H, F, w.clspre, H, nullptr, 0, B, ncu, st);
+            if (p16) rc = launch_gemm<EPI_BIAS_F16>(w.ffn, F, Ly.w2, Ly.b2, B, nullptr, H, F, clspre16, H, nullptr, 0, B, ncu, st);
+            else if (r32) rc = launch_gemm<EPI_BIAS_F32>(w.ffn, F, Ly.w2, Ly.b2, B, nullptr, H, F, w.clspre, H, nullptr, 0, B, ncu, st);
             else rc = launch_gemm<EPI_BIAS_RES_F32>(w.ffn, F, Ly.w2, Ly.b2, B, nullptr, H, F, w.clspre, H, w.cls16, H, B, ncu, st, &res_in);
             if (rc) return rc;
             post_ln(w.clspre, res_in, w.cls16, w.cls32, B, nullptr, Ly.ln2_g, Ly.ln2_b, w.cls16, w.cls32);
@@ -474,13 +484,15 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
         else rc = launch_attention<32>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         if (rc) return rc;
         bool res_in = true;
-        if (r32) rc = launch_gemm<EPI_BIAS_F32>(w.ctx, H, Ly.wo, Ly.bo, Tcap, w.total, H, H, w.pre, H, nullptr, 0, Test, ncu, st);
+        if (p16) rc = launch_gemm<EPI_BIAS_F16>(w.ctx, H, Ly.wo, Ly.bo, Tcap, w.total, H, H, pre16, H, nullptr, 0, Test, ncu, st);
+        else if (r32) rc = launch_gemm<EPI_BIAS_F32>(w.ctx, H, Ly.wo, Ly.bo, Tcap, w.total, H, H, w.pre, H, nullptr, 0, Test, ncu, st);
         else rc = launch_gemm<EPI_BIAS_RES_F32>(w.ctx, H, Ly.wo, Ly.bo, Tcap, w.total, H, H, w.pre, H, w.h16, H, Test, ncu, st, &res_in);
         if (rc) return rc;
         post_ln(w.pre, res_in, w.h16, w.h32, Tcap, w.total, Ly.ln1_g, Ly.ln1_b, w.h16, w.h32);
         rc = launch_gemm<EPI_BIAS_GELU_F16>(w.h16, H, Ly.w1, Ly.b1, Tcap, w.total, F, H, w.ffn, F, nullptr, 0, Test, ncu, st);
         if (rc) return rc;
-        if (r32) rc = launch_gemm<EPI_BIAS_F32>(w.ffn, F, Ly.w2, Ly.b2, Tcap, w.total, H, F, w.pre, H, nullptr, 0, Test, ncu, st);
+        if (p16) rc = launch_gemm<EPI_BIAS_F16>(w.ffn, F, Ly.w2, Ly.b2, Tcap, w.total, H, F, pre16, H, nullptr, 0, Test, ncu, st);
+        else if (r32) rc = launch_gemm<EPI_BIAS_F32>(w.ffn, F, Ly.w2, Ly.b2, Tcap, w.total, H, F, w.pre, H, nullptr, 0, Test, ncu, st);
         else rc = launch_gemm<EPI_BIAS_RES_F32>(w.ffn, F, Ly.w2, Ly.b2, Tcap, w.total, H, F, w.pre, H, w.h16, H, Test, ncu, st, &res_in);
         if (rc) return rc;
         post_ln(w.pre, res_in, w.h16, w.h32, Tcap, w.total, Ly.ln2_g, Ly.ln2_b, w.h16, w.h32);
@@ -488,7 +500,7 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
     }
     rc = launch_gemm<EPI_BIAS_F32>(w.cls16, H, h->wproj, h->bproj, B, nullptr, H, H, w.clspre, H, nullptr, 0, B, ncu, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, (const _Float16*)nullptr, (const float*)nullptr, B,
+    hipLaunchKernelGGL(layernorm_kernel<float>, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)w.clspre, (const _Float16*)nullptr, (const float*)nullptr, B,
                        (const int*)nullptr, H, (const float*)h->lnp_g, (const float*)h->lnp_b, c.ln_eps, (_Float16*)nullptr, out_dev);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;

@@ -124,14 +124,17 @@ embed_ln_kernel(const long long* __restrict__ ids, const int* __restrict__ tok_s
 // residual_fp32 mode, or the final embedding); one wave per row, 16-byte loads (H % 256 == 0 fast path).
 // `res16` / `res32` (at most one): residual added before normalising, when the producing GEMM left it out. out32 may alias
 // res32 (a wave reads its whole row before it writes it).
+// IN_T = float: the producing GEMM left its sums in fp32; IN_T = _Float16 (mdr_encoder_config.residual_fp32 = 2): the Linear's output was rounded to
+// fp16 as apex O1's F.linear does, half the bytes in and out of the GEMM epilogue.
+template <typename IN_T>
 __global__ void __launch_bounds__(256)
-layernorm_kernel(const float* __restrict__ in, const _Float16* __restrict__ res16, const float* res32, int rows_cap, const int* __restrict__ rows_dev,
+layernorm_kernel(const IN_T* __restrict__ in, const _Float16* __restrict__ res16, const float* res32, int rows_cap, const int* __restrict__ rows_dev,
                  int H, const float* __restrict__ g, const float* __restrict__ bta, float eps, _Float16* __restrict__ out16, float* out32) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rows = rows_dev ? min(*rows_dev, rows_cap) : rows_cap;
     if (t >= rows) return;
-    const float* r = in + (size_t)t * H;
+    const IN_T* r = in + (size_t)t * H;
     if ((H & 255) == 0) {
         const int n4 = H >> 8;  // float4 per lane (<= 4)
         f32x4 x[4];
@@ -139,7 +142,13 @@ layernorm_kernel(const float* __restrict__ in, const _Float16* __restrict__ res1
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < n4) {
-                x[i] = *(const f32x4*)(r + (lane + 64 * i) * 4);
+                if constexpr (std::is_same<IN_T, float>::value) {
+                    x[i] = *(const f32x4*)(r + (lane + 64 * i) * 4);
+                } else {
+                    const half4 h4 = *(const half4*)(r + (lane + 64 * i) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[i][j] = (float)h4[j];
+                }
                 if (res16) {
                     const half4 r4 = *(const half4*)(res16 + (size_t)t * H + (lane + 64 * i) * 4);
 #pragma unroll
@@ -181,7 +190,7 @@ layernorm_kernel(const float* __restrict__ in, const _Float16* __restrict__ res1
 #pragma unroll
     for (int i = 0; i < kMaxPerLane; ++i)
         if (i < n) {
-            x[i] = r[lane + 64 * i] + (res16 ? (float)res16[(size_t)t * H + lane + 64 * i] : 0.f) + (res32 ? res32[(size_t)t * H + lane + 64 * i] : 0.f);
+            x[i] = (float)r[lane + 64 * i] + (res16 ? (float)res16[(size_t)t * H + lane + 64 * i] : 0.f) + (res32 ? res32[(size_t)t * H + lane + 64 * i] : 0.f);
             s += x[i];
         }
     const float mu = wave_sum(s) / H;

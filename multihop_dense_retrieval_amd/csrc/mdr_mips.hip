@@ -913,4 +913,25 @@ int mdr_topk_merge(const float* D_parts_dev, const int64_t* I_parts_dev, int npa
     return MDR_OK;
 }
 
+size_t mdr_topk_packed_ids_offset(int nq, int k) {
+    if (nq < 0 || k < 1) return 0;
+    return align_up((size_t)nq * (size_t)k * 4, 8);
+}
+
+size_t mdr_topk_packed_bytes(int nq, int k) {
+    if (nq < 0 || k < 1) return 0;
+    return align_up(mdr_topk_packed_ids_offset(nq, k) + (size_t)nq * (size_t)k * 8, 256);
+}
+
+int mdr_topk_merge_packed(const void* packed_parts_dev, int nparts, int nq, int k, float* D_dev, int64_t* I_dev, void* stream) {
+    MDR_REQUIRE(nparts >= 1 && nq >= 0 && k >= 1 && k <= kKMax, "bad merge shape nparts=%d nq=%d k=%d", nparts, nq, k);
+    if (nq == 0) return MDR_OK;
+    MDR_REQUIRE(packed_parts_dev && D_dev && I_dev, "NULL pointer");
+    MDR_REQUIRE(((uintptr_t)packed_parts_dev & 7) == 0, "packed blocks must be 8-byte aligned");
+    hipLaunchKernelGGL(merge_packed_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, (const char*)packed_parts_dev, (long long)mdr_topk_packed_bytes(nq, k),
+                       (long long)mdr_topk_packed_ids_offset(nq, k), nparts, nq, k, D_dev, (long long*)I_dev);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
 }  // extern "C"

@@ -143,3 +143,44 @@ merge_parts_kernel(const float* __restrict__ Dp, const long long* __restrict__ I
         if (rank < k) { D[(size_t)q * k + rank] = s; I[(size_t)q * k + rank] = id; }
     }
 }
+
+// cross-shard merge of PACKED per-rank blocks (mdr_topk_merge_packed): part p = [scores f32 nq*k | pad to 8 B | ids i64 nq*k], `part_stride` bytes apart
+// (what one all_gather of every rank's search output delivers). The nparts*k candidates of a query are staged in LDS once; the same order rule as
+// merge_parts_kernel (score desc, id asc, position asc), no assumption that a part is sorted. kMergePackedLds entries fit; larger T take the global path.
+constexpr int kMergePackedLds = 4096;
+__global__ void __launch_bounds__(256)
+merge_packed_kernel(const char* __restrict__ parts, long long part_stride, long long ids_off, int nparts, int nq, int k, float* __restrict__ D,
+                    long long* __restrict__ I) {
+    __shared__ float s_sc[kMergePackedLds];
+    __shared__ long long s_id[kMergePackedLds];
+    const int q = blockIdx.x;
+    const int T = nparts * k;
+    const bool in_lds = T <= kMergePackedLds;
+    for (int i = threadIdx.x; i < k; i += 256) { D[(size_t)q * k + i] = -FLT_MAX; I[(size_t)q * k + i] = -1; }
+    auto score_at = [&](int i) { int p = i / k, e = i - p * k; return ((const float*)(parts + p * part_stride))[(size_t)q * k + e]; };
+    auto id_at = [&](int i) { int p = i / k, e = i - p * k; return ((const long long*)(parts + p * part_stride + ids_off))[(size_t)q * k + e]; };
+    if (in_lds)
+        for (int i = threadIdx.x; i < T; i += 256) { s_sc[i] = score_at(i); s_id[i] = id_at(i); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += 256) {
+        const float s = in_lds ? s_sc[i] : score_at(i);
+        const long long id = in_lds ? s_id[i] : id_at(i);
+        if (id < 0) continue;
+        int rank = 0;
+        if (in_lds) {
+            for (int j = 0; j < T; ++j) {
+                const long long idj = s_id[j];
+                const float sj = s_sc[j];
+                rank += (idj >= 0) && ((sj > s) || (sj == s && (idj < id || (idj == id && j < i))));
+            }
+        } else {
+            for (int j = 0; j < T; ++j) {
+                const long long idj = id_at(j);
+                if (idj < 0) continue;
+                const float sj = score_at(j);
+                rank += (sj > s) || (sj == s && (idj < id || (idj == id && j < i)));
+            }
+        }
+        if (rank < k) { D[(size_t)q * k + rank] = s; I[(size_t)q * k + rank] = id; }
+    }
+}

@@ -73,6 +73,24 @@ def encode_pairs_2_11(tokenizer, firsts, seconds, max_length, pad_to_max_length)
     return ids_out, mask_out
 
 
+def tokenize_2_11(tokenizer, texts, pairs, max_length):
+    """`batch_encode_plus(x, max_length=n, pad_to_max_length=True, return_tensors="pt")` of transformers 2.11
+    (eval_mhop_retrieval.py:148,168): `<s> q </s>` / `<s> q </s></s> d </s>`, longest-first truncation, right-pad to
+    max_length. RoBERTa-family tokenizers (the reference's path): single texts go through the installed tokenizer's own call
+    with 2.11's prefix space in front (prefix_space_2_11), pairs through encode_pairs_2_11, which also keeps the
+    reference's (slow-tokenizer) truncation rule for odd token budgets. Any other family (the reference's `else` branches for
+    BERT-style models): the installed tokenizer's own pair call, `[CLS] a [SEP] b [SEP]` with token_type_ids."""
+    if not is_roberta_family(tokenizer):
+        if pairs is None:
+            return tokenizer(list(texts), max_length=max_length, padding="max_length", truncation=True, return_tensors="pt")
+        return tokenizer([p[0] for p in pairs], [p[1] for p in pairs], max_length=max_length, padding="max_length",
+                         truncation="longest_first", return_tensors="pt")
+    if pairs is None:
+        return tokenizer([prefix_space_2_11(t) for t in texts], max_length=max_length, padding="max_length", truncation=True, return_tensors="pt")
+    ids, mask = encode_pairs_2_11(tokenizer, [p[0] for p in pairs], [p[1] for p in pairs], max_length, True)
+    return {"input_ids": torch.tensor(ids, dtype=torch.int64), "attention_mask": torch.tensor(mask, dtype=torch.int64)}
+
+
 def collate_tokens(values, pad_idx, eos_idx=None, left_pad=False, move_eos_to_beginning=False):
     """List of 1-D tensors -> one right- (or left-) padded 2-D tensor."""
     values = [v.reshape(-1) for v in values]

@@ -4,8 +4,10 @@ lines and JSONL output; the encoder and the index run on MI355X through libmdrhi
     python scripts/eval/eval_mhop_retrieval.py ${EVAL_DATA} ${CORPUS_VECTOR_PATH} ${CORPUS_DICT} ${MODEL_CHECKPOINT} \
         --batch-size 100 --beam-size 1 --topk 1 --shared-encoder --model-name roberta-base --gpu --save-path ${OUT}
 
-Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N ...`; the index is row-sharded
-over the ranks (one RCCL all_gather of per-shard top-k per hop), rank 0 logs and writes the output.
+Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N ...`; the index is row-sharded over the
+ranks AND the question batches are partitioned over them (rank r owns batches r, r+N, ...: 1/N of the encoder
+forwards per GPU; per hop one all_gather of the query embeddings and one of the per-shard top-k lists, pipeline.py);
+rank 0 collects the records in input order, logs and writes the output.
 
 Differences from the reference, all deliberate: `--gpu` is implied (there is no CPU
 path) and no device id is hard-coded; `--hnsw` is rejected (approximate search is out of scope);
@@ -24,7 +26,7 @@ import torch
 
 from . import answer_recall, mhop
 from .index import IndexFlatIP, ShardedIndexFlatIP
-from .retriever import RobertaConfig, RobertaRetriever, load_saved, move_to_cuda
+from .retriever import RobertaConfig, RobertaRetriever, load_saved, move_to_cuda  # noqa: F401  (move_to_cuda: re-exported, utils.py:24-41)
 
 logger = logging.getLogger()
 
@@ -61,6 +63,11 @@ def build_parser():
     p.add_argument("--hop2-on-device", action="store_true")
     # extension: software-pipelined batch loop (hop 2 of batch i beside hop 1 of batch i+1; identical results)
     p.add_argument("--pipeline-batches", action="store_true")
+    # extension: batches in flight in the host/device software pipeline (pipeline.py; default: 2 with --hop2-on-device, else 4)
+    p.add_argument("--inflight", type=int, default=None)
+    # multi-GPU launches (torch.distributed.run): "nccl" is RCCL; gloo (+ --share-gpu: every rank on cuda:0) exists for the tests
+    p.add_argument("--dist-backend", default="nccl")
+    p.add_argument("--share-gpu", action="store_true")
     return p
 
 
@@ -82,23 +89,7 @@ def _load_config(model_name):
     return RobertaConfig()
 
 
-def _tokenize(tokenizer, texts, pairs, max_length):
-    """`batch_encode_plus(x, max_length=n, pad_to_max_length=True, return_tensors="pt")` of transformers 2.11
-    (eval_mhop_retrieval.py:148,168): `<s> q </s>` / `<s> q </s></s> d </s>`, longest-first truncation, right-pad to
-    max_length. RoBERTa-family tokenizers (the reference's path): single texts go through the installed tokenizer's own call
-    with 2.11's prefix space in front (data.prefix_space_2_11), pairs through data.encode_pairs_2_11, which also keeps the
-    reference's (slow-tokenizer) truncation rule for odd token budgets. Any other family (the reference's `else` branches for
-    BERT-style models): the installed tokenizer's own pair call, `[CLS] a [SEP] b [SEP]` with token_type_ids."""
-    from .data import encode_pairs_2_11, is_roberta_family, prefix_space_2_11
-    if not is_roberta_family(tokenizer):
-        if pairs is None:
-            return tokenizer(list(texts), max_length=max_length, padding="max_length", truncation=True, return_tensors="pt")
-        return tokenizer([p[0] for p in pairs], [p[1] for p in pairs], max_length=max_length, padding="max_length",
-                         truncation="longest_first", return_tensors="pt")
-    if pairs is None:
-        return tokenizer([prefix_space_2_11(t) for t in texts], max_length=max_length, padding="max_length", truncation=True, return_tensors="pt")
-    ids, mask = encode_pairs_2_11(tokenizer, [p[0] for p in pairs], [p[1] for p in pairs], max_length, True)
-    return {"input_ids": torch.tensor(ids, dtype=torch.int64), "attention_mask": torch.tensor(mask, dtype=torch.int64)}
+from .data import tokenize_2_11 as _tokenize  # noqa: E402  (the tests and the FEVER script import it from here)
 
 
 def load_corpus(corpus_dict, use_store, rank=0, world=1):
@@ -150,20 +141,40 @@ def load_index(indexpath, d=768, storage="f32"):
     return index
 
 
+LAST_RUN = {}  # timing / counters of the last main() call of this process (bench.py --mode cli and the tests read it)
+
+
 def main(argv=None, tokenizer=None):
     args = build_parser().parse_args(argv)
     _setup_logging()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not torch.distributed.is_initialized():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        torch.distributed.init_process_group("nccl")
-    if rank != 0:
-        logger.setLevel(logging.WARNING)
     if args.hnsw:
         raise SystemExit("--hnsw (approximate HNSW search) is not implemented: this build is the exact flat-IP path only")
     if args.save_index:
         raise SystemExit("--save-index wrote a FAISS file to a hard-coded path in the reference; not supported here")
+    if rank != 0:
+        logger.setLevel(logging.WARNING)
+    # the tokenizer and its worker processes come FIRST: the workers are forked before this process touches the device
+    if tokenizer is None:
+        from transformers import AutoTokenizer
+        tokenizer = AutoTokenizer.from_pretrained(args.model_name)
+    from .pipeline import TokenizerPool
+    pool = TokenizerPool(tokenizer, args.num_workers)
+    try:
+        return _run(args, tokenizer, pool, world, rank)
+    finally:
+        pool.close()
+
+
+def _run(args, tokenizer, pool, world, rank):
+    import time
+
+    from .pipeline import TwoHopPipeline, gather_results
+    dist = torch.distributed
+    if world > 1 and not dist.is_initialized():
+        torch.cuda.set_device(0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(args.dist_backend)
 
     logger.info("Loading data...")
     with open(args.raw_data) as f:
@@ -173,13 +184,11 @@ def main(argv=None, tokenizer=None):
 
     logger.info("Loading trained model...")
     bert_config = _load_config(args.model_name)
-    if tokenizer is None:
-        from transformers import AutoTokenizer
-        tokenizer = AutoTokenizer.from_pretrained(args.model_name)
     model = RobertaRetriever(bert_config, args)
     model = load_saved(model, args.model_path, exact=False)
     model.to(torch.device("cuda"))
     model.eval()
+    model.capture_on_first_use = True  # the loop repeats two shapes (B x max_q_len, B*beam x max_q_sp_len): their hipGraphs are captured at the first batch
 
     logger.info("Building index...")
     index = load_index(args.indexpath, d=bert_config.hidden_size, storage=args.index_storage)
@@ -188,93 +197,68 @@ def main(argv=None, tokenizer=None):
     id2doc = load_corpus(args.corpus_dict, args.corpus_store, rank, world)
     logger.info(f"Corpus size {len(id2doc)}")
 
+    roberta = "roberta" in args.model_name
     arena = None
     if args.hop2_on_device:
-        from .arena import TokenArena
+        from .arena import TokenArena, arena_tag
         cache = args.corpus_dict + ".arena.npz"
-        if os.path.exists(cache):
-            arena = TokenArena.load(cache)
-        else:
-            logger.info("Tokenising the corpus once for device-side hop-2 assembly...")
-            arena = TokenArena.from_corpus(id2doc, tokenizer, roberta="roberta" in args.model_name, max_tokens=args.max_q_sp_len)
+        tag = arena_tag(tokenizer, roberta, args.max_q_sp_len)
+        arena = TokenArena.load(cache, expect_tag=tag) if os.path.exists(cache) else None  # None: written under another tokenisation rule
+        stale = torch.tensor([0 if arena is not None else 1])
+        if world > 1:  # every rank must take the same branch (a rank that sees the fresh file later must not skip the barrier)
+            stale = stale.cuda() if dist.get_backend() == "nccl" else stale
+            dist.all_reduce(stale, op=dist.ReduceOp.MAX)
+        if int(stale.item()):
             if rank == 0:
-                arena.save(cache)
+                logger.info("Tokenising the corpus once for device-side hop-2 assembly...")
+                arena = TokenArena.from_corpus(id2doc, tokenizer, roberta=roberta, max_tokens=args.max_q_sp_len)
+                arena.save(cache, tag=tag)
+            if world > 1:
+                dist.barrier()
+                if rank != 0:
+                    arena = TokenArena.load(cache, expect_tag=tag)
         arena = arena.to(torch.device("cuda"))
 
     logger.info("Encoding questions and searching")
     questions = [mhop.strip_question(it["question"]) for it in ds_items]
-    metrics, retrieval_outputs = [], []
-    roberta = "roberta" in args.model_name
-
-    def hop1_inputs(batch_q):
-        return move_to_cuda(dict(_tokenize(tokenizer, batch_q, None, args.max_q_len)))
-
-    def hop2_embeds(batch_q, D, I):
-        """Hop-2 query embeddings of one batch from its hop-1 results (device tensors). Returns (q_sp_embeds, D, I as numpy);
-        D carries the -inf of empty passages afterwards, as in the reference (:162-165)."""
-        if arena is not None:
-            # questions re-encoded without the hop-1 length cap so the pair sees the same tokens the tokenizer would
-            qfull = move_to_cuda(dict(_tokenize(tokenizer, batch_q, None, args.max_q_sp_len)))
-            ids2, mask2 = arena.assemble_hop2(qfull["input_ids"], qfull["attention_mask"], I, D, args.max_q_sp_len)
-            return model.encode_q(ids2, mask2, None), D.cpu().numpy(), I.cpu().numpy()
-        D, I = D.cpu().numpy(), I.cpu().numpy()
-        pairs = mhop.build_hop2_pairs(batch_q, D, I, id2doc, roberta=roberta)
-        enc2 = move_to_cuda(dict(_tokenize(tokenizer, None, pairs, args.max_q_sp_len)))
-        return model.encode_q(enc2["input_ids"], enc2["attention_mask"], enc2.get("token_type_ids", None)), D, I
 
     def finish_batch(batch_ann, D, I, D_, I_):
+        """Path ranking, metrics and output records of one batch (eval_mhop_retrieval.py:181-258); runs on the finisher thread."""
         chains = mhop.rank_paths(D, I, D_, I_, args.beam_size, args.topk)
+        ms, recs = [], []
         for ann, ch in zip(batch_ann, chains):
             if args.only_eval_ans:  # answer-string recall over the retrieved chains; nothing is saved (:208-217)
-                metrics.append(answer_recall.answer_metrics(ann, ch, id2doc))
+                ms.append(answer_recall.answer_metrics(ann, ch, id2doc))
                 continue
             m = mhop.question_metrics(ch, ann["sp"], id2doc)
             m.update(question=ann["question"], type=ann["type"])
-            metrics.append(m)
-            retrieval_outputs.append(mhop.output_record(ann, ch, id2doc))
+            ms.append(m)
+            recs.append(mhop.output_record(ann, ch, id2doc))
+        return ms, recs
 
-    starts = list(range(0, len(questions), args.batch_size))
-    if not args.pipeline_batches:
-        for b_start in starts:
-            with torch.no_grad():
-                batch_q = questions[b_start:b_start + args.batch_size]
-                batch_ann = ds_items[b_start:b_start + args.batch_size]
-                enc = hop1_inputs(batch_q)
-                q_embeds = model.encode_q(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids", None))
-                D, I = index.search(q_embeds, args.beam_size)
-                q_sp_embeds, D, I = hop2_embeds(batch_q, D, I)
-                D_, I_ = index.search(q_sp_embeds, args.beam_size)
-                finish_batch(batch_ann, D, I, D_.cpu().numpy(), I_.cpu().numpy())
-    elif starts:
-        # Software-pipelined loop (same results, batch for batch): batches are independent, so while batch i is in hop 2 the
-        # questions of batch i+1 are encoded on a side stream (second encoder lane) and ONE search call serves the hop-2
-        # queries of batch i together with the hop-1 queries of batch i+1 (more than 128 queries go 256 per corpus pass).
-        side = torch.cuda.Stream()
-        with torch.no_grad():
-            bq = questions[starts[0]:starts[0] + args.batch_size]
-            enc = hop1_inputs(bq)
-            D, I = index.search(model.encode_q(enc["input_ids"], enc["attention_mask"], None), args.beam_size)
-            for n, b_start in enumerate(starts):
-                batch_q = questions[b_start:b_start + args.batch_size]
-                batch_ann = ds_items[b_start:b_start + args.batch_size]
-                nxt = questions[starts[n + 1]:starts[n + 1] + args.batch_size] if n + 1 < len(starts) else None
-                q_next = None
-                if nxt is not None:
-                    enc_n = hop1_inputs(nxt)
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        q_next = model.encode_q(enc_n["input_ids"], enc_n["attention_mask"], None, lane=1)
-                q_sp_embeds, Dn, In = hop2_embeds(batch_q, D, I)
-                nsp = q_sp_embeds.shape[0]
-                if q_next is not None:
-                    torch.cuda.current_stream().wait_stream(side)
-                    q_next.record_stream(torch.cuda.current_stream())
-                    Dc, Ic = index.search(torch.cat([q_sp_embeds, q_next], 0), args.beam_size)
-                else:
-                    Dc, Ic = index.search(q_sp_embeds, args.beam_size)
-                finish_batch(batch_ann, Dn, In, Dc[:nsp].cpu().numpy(), Ic[:nsp].cpu().numpy())
-                if q_next is not None:
-                    D, I = Dc[nsp:].contiguous(), Ic[nsp:].contiguous()
+    pipe = TwoHopPipeline(model, index, pool, id2doc, finish_batch, batch_size=args.batch_size, beam=args.beam_size, max_q_len=args.max_q_len,
+                          max_q_sp_len=args.max_q_sp_len, roberta=roberta, arena=arena, device=torch.device("cuda", torch.cuda.current_device()),
+                          rank=rank, world=world, depth=args.inflight, fuse=args.pipeline_batches)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    mine = pipe.run(questions, ds_items)
+    fence()
+    loop_s = time.perf_counter() - t0
+    results = gather_results(mine, world)
+    LAST_RUN.clear()
+    LAST_RUN.update(loop_seconds=loop_s, questions=len(questions), world=world, rank=rank, stats=dict(pipe.stats),
+                    encoder_forward_calls=model.forward_calls, encoder_forward_rows=model.forward_rows,
+                    graph_captures=model.graph_captures, graph_replays=model.graph_replays)
+    if results is None:  # ranks other than 0: their part went to rank 0
+        return [m for _, (ms, _) in sorted(mine, key=lambda t: t[0]) for m in ms], [r for _, (_, rs) in sorted(mine, key=lambda t: t[0]) for r in rs]
+    metrics = [m for ms, _ in results for m in ms]
+    retrieval_outputs = [r for _, rs in results for r in rs]
 
     if args.save_path != "" and rank == 0:
         with open(args.save_path, "w") as out:

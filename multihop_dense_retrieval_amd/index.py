@@ -107,6 +107,19 @@ class IndexFlatIP:
                                       self._ws.numel(), _lib.current_stream_ptr(self.device)))
         return D, I
 
+    def search_device_packed(self, q, k):
+        """search_device() writing (D, I) straight into ONE packed block (mdr_topk_packed_bytes: scores at offset 0, ids at
+        mdr_topk_packed_ids_offset) -- the unit the sharded search all-gathers, so the exchange needs no glue kernels.
+        -> (block uint8 [bytes], D view float32 [nq, k], I view int64 [nq, k])."""
+        L = _lib.lib()
+        nq, k = int(q.shape[0]), int(k)
+        nbytes, off = int(L.mdr_topk_packed_bytes(nq, k)), int(L.mdr_topk_packed_ids_offset(nq, k))
+        block = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=self.device)
+        D = block[: nq * k * 4].view(torch.float32).view(nq, k)
+        I = block[off: off + nq * k * 8].view(torch.int64).view(nq, k)
+        self.search_device(q, k, out=(D, I))
+        return block, D, I
+
     # -- extras ------------------------------------------------------------------------------------------
     def stream_bytes(self):
         """HBM bytes one search call reads for the corpus (algorithmic bytes of the roofline)."""
@@ -154,6 +167,16 @@ def topk_merge(D_parts, I_parts):
     _lib.check(_lib.lib().mdr_topk_merge(ctypes.c_void_p(D_parts.data_ptr()), ctypes.c_void_p(I_parts.data_ptr()), P, nq, k,
                                          ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
                                          _lib.current_stream_ptr(D_parts.device)))
+    return D, I
+
+
+def topk_merge_packed(blocks, nparts, nq, k):
+    """blocks: uint8 cuda [nparts * mdr_topk_packed_bytes(nq, k)] (the all-gathered search_device_packed() blocks of the ranks)
+    -> merged (D [nq, k], I [nq, k]); ONE kernel, no unpacking (mdr_topk_merge_packed)."""
+    D = torch.empty((nq, k), dtype=torch.float32, device=blocks.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=blocks.device)
+    _lib.check(_lib.lib().mdr_topk_merge_packed(ctypes.c_void_p(blocks.data_ptr()), int(nparts), int(nq), int(k), ctypes.c_void_p(D.data_ptr()),
+                                                ctypes.c_void_p(I.data_ptr()), _lib.current_stream_ptr(blocks.device)))
     return D, I
 
 
@@ -228,6 +251,20 @@ class ShardedIndexFlatIP:
             return Dm.cpu().numpy(), Im.cpu().numpy()
         D, I = self.local.search(q, k)
         return self.search_gathered(D, I, force=force)
+
+    def search_device(self, q, k, force=False):
+        """Device tensors in, device tensors out, no sync: this rank's shard is searched with the results written straight into the
+        packed exchange block, ONE all-gather (RCCL over xGMI) moves every rank's block, ONE kernel merges them (mdr_topk_merge_packed)
+        -- besides the search itself the hop costs one collective and one launch. Identical on all ranks."""
+        if self.world == 1 and not (force and self.dist.is_initialized()):
+            return self.local.search_device(q, k)
+        nq = int(q.shape[0])
+        if not hasattr(self.local, "search_device_packed"):  # an injected test double (CPU tests): the generic exchange + merge_fn
+            D, I = self.local.search(q, k)
+            return self.search_gathered(D, I, force=force)
+        block, _, _ = self.local.search_device_packed(q, k)
+        gathered = all_gather_dim0(block, self.world, self.group)
+        return topk_merge_packed(gathered, self.world, nq, k)
 
     def search_gathered(self, D, I, force=False):
         """Exchange this rank's (D, I) [nq, k] with every other rank and merge; identical on all ranks.

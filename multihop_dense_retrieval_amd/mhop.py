@@ -132,7 +132,7 @@ class SyntheticTwoHop:
     VOCAB = 50265
 
     def __init__(self, index, batch, beam, topk, dim, device, max_q_len=70, max_q_sp_len=350, use_encoder=True,
-                 planted_rows=None, rank=0, world=1, weak=False, pipelined=False):
+                 planted_rows=None, rank=0, world=1, weak=False, pipelined=False, pool=1):
         """`weak=False`: ONE batch of `batch` questions shared by all ranks (strong scaling: the encoder work is split).
         `weak=True`: every rank owns its own batch of `batch` questions (global batch = batch * world): it encodes them,
         the embeddings of all ranks are all-gathered, every rank searches ALL of them in its row shard, the per-shard
@@ -148,15 +148,23 @@ class SyntheticTwoHop:
         self.local = getattr(index, "local", index)
         g = torch.Generator(device=device).manual_seed(2 + (1000 * rank if self.weak else 0))
         B = batch
-        self.q_len = torch.randint(8, 41, (B,), generator=g, device=device)
-        self.q_ids = torch.randint(3, self.VOCAB, (B, self.Lq), generator=g, device=device)
+        # `pool` DIFFERENT question batches, walked round-robin by step(): different lengths and tokens -> different hop-1 answers ->
+        # different hop-2 token totals (the GEMM tile counts move with them); pool = 1 repeats one batch (rounds 1-3)
+        self.pool = max(1, int(pool))
+        self.batches = []
         pos = torch.arange(self.Lq, device=device)[None, :]
-        self.q_mask = (pos < self.q_len[:, None]).long()
-        self.q_ids = torch.where(pos == 0, torch.zeros_like(self.q_ids), self.q_ids)
-        self.q_ids = torch.where(pos == self.q_len[:, None] - 1, torch.full_like(self.q_ids, 2), self.q_ids)
-        self.q_ids = torch.where(self.q_mask.bool(), self.q_ids, torch.ones_like(self.q_ids))
-        self.noise = 0.05 * torch.randn((B, dim), generator=g, device=device)
+        for _ in range(self.pool):
+            q_len = torch.randint(8, 41, (B,), generator=g, device=device)
+            q_ids = torch.randint(3, self.VOCAB, (B, self.Lq), generator=g, device=device)
+            q_mask = (pos < q_len[:, None]).long()
+            q_ids = torch.where(pos == 0, torch.zeros_like(q_ids), q_ids)
+            q_ids = torch.where(pos == q_len[:, None] - 1, torch.full_like(q_ids, 2), q_ids)
+            q_ids = torch.where(q_mask.bool(), q_ids, torch.ones_like(q_ids))
+            noise = 0.05 * torch.randn((B, dim), generator=g, device=device)
+            self.batches.append({"q_len": q_len, "q_ids": q_ids, "q_mask": q_mask, "noise": noise})
+        self._cur = 0  # pool entry of the batch step() works on (pipelined: the batch whose hop 2 runs)
         self.table = torch.randn((1024, dim), generator=g, device=device)
+        self.step_log = []  # per step: (pool entry, hop-2 sequence lengths [B*beam] as a device tensor or None)
         self.planted_rows = planted_rows
         self.encoder = None
         self.arena = None
@@ -167,6 +175,26 @@ class SyntheticTwoHop:
             self.arena = TokenArena.synthetic(int(index.ntotal), device, seed=5, vocab=self.VOCAB)
         self._ev = []
         self._search_ev = []
+
+    # -- the current batch of the pool ------------------------------------------------------------------------
+    @property
+    def q_len(self):
+        return self.batches[self._cur]["q_len"]
+
+    @property
+    def q_ids(self):
+        return self.batches[self._cur]["q_ids"]
+
+    @property
+    def q_mask(self):
+        return self.batches[self._cur]["q_mask"]
+
+    @property
+    def noise(self):
+        return self.batches[self._cur]["noise"]
+
+    def _nxt(self):
+        return self.batches[(self._cur + 1) % self.pool]
 
     # -- hop-2 inputs: assembled on the device from the (synthetic) token arena -----------------------------
     def _hop2_inputs(self, I, D=None):
@@ -260,8 +288,9 @@ class SyntheticTwoHop:
             start = torch.cuda.Event()
             start.record()
             self._side.wait_event(start)
+            nb = self._nxt()
             with torch.cuda.stream(self._side):
-                q_next = self._encode(self.q_ids, self.q_mask, lane=1)
+                q_next = self._encode(nb["q_ids"], nb["q_mask"], lane=1)
                 done = torch.cuda.Event()
                 done.record()
             ids, mask = self._hop2_inputs(I, D)  # hop-2 inputs of batch i
@@ -274,7 +303,7 @@ class SyntheticTwoHop:
             ids = mask = None
             ev.append(self._mark())
             q2 = (0.5 * q).repeat_interleave(bm, 0) + self.table[(I.reshape(-1) % 1024)]
-            e = torch.cat([q2, self.planted_rows + self.noise], 0).contiguous()
+            e = torch.cat([q2, self.planted_rows + self._nxt()["noise"]], 0).contiguous()
             if self.weak:
                 from .index import all_gather_dim0
                 e = all_gather_dim0(e, self.world)
@@ -289,6 +318,8 @@ class SyntheticTwoHop:
         h1, h2, sc = rank_paths_device(D, I, D2, I2, bm, self.topk)
         ev.append(self._mark())
         self._ev.append(ev)
+        self.step_log.append((self._cur, mask.sum(1) if mask is not None else None))
+        self._cur = (self._cur + 1) % self.pool
         return {"q": q, "q2": q2, "D": D, "I": I, "D2": D2, "I2": I2, "hop1": h1, "hop2": h2, "score": sc, "ids2": ids, "mask2": mask}
 
     def step(self):
@@ -326,12 +357,24 @@ class SyntheticTwoHop:
         ev.append(self._mark())
         self._ev.append(ev)
         self.last_token_counts = (int(self.Lq), int(self.Lsp))
+        self.step_log.append((self._cur, mask.sum(1) if self.use_encoder else None))
+        self._cur = (self._cur + 1) % self.pool
         return {"q": q, "q2": q2 if not self.weak else self._own(q2), "D": D, "I": I, "D2": D2, "I2": I2, "hop1": h1, "hop2": h2, "score": s,
                 "ids2": ids if self.use_encoder else None, "mask2": mask if self.use_encoder else None}
 
     # -- reporting -----------------------------------------------------------------------------------------
     def reset_kernel_timers(self):
-        self._ev, self._search_ev = [], []
+        self._ev, self._search_ev, self.step_log = [], [], []
+
+    def per_step(self):
+        """[(ms, pool entry, hop-2 tokens, hop-2 sequence lengths)] of the timed steps but the last: a step's time runs from its first event to the
+        next step's (the main stream is one sequence of steps)."""
+        out = []
+        for i in range(len(self._ev) - 1):
+            ent, lens = self.step_log[i]
+            lens = None if lens is None else lens.cpu().numpy()
+            out.append((float(self._ev[i][0].elapsed_time(self._ev[i + 1][0])), ent, None if lens is None else int(lens.sum()), lens))
+        return out
 
     def search_kernel_ms(self):
         if not self._search_ev:

@@ -1,0 +1,373 @@
+"""The batch loop of /root/reference/scripts/eval/eval_mhop_retrieval.py:142-263 as a software pipeline over batches and ranks.
+
+The reference walks one batch at a time on one GPU: tokenise -> encode -> search -> (host) build pairs -> tokenise -> encode ->
+search -> rank paths -> metrics, every stage waiting for the previous one. The arithmetic of a batch takes ~6 ms on an MI355X;
+tokenising its 100 questions alone takes longer than that on one host core. This module keeps the GPU busy without changing
+what any batch computes:
+
+  * host work leaves the GPU's critical path: question tokenisation (and, on the host-tokenizer path, the hop-2 pair
+    tokenisation) runs in `--num-workers` forked worker processes (the reference's flag, unused there); path ranking, metrics
+    and the JSONL records of batch i-1 are produced by a finisher thread while the GPU runs batch i; every result crosses to
+    the host exactly once per batch, through pinned memory, behind an event (no `.cpu()` between the hops on the
+    `--hop2-on-device` path);
+  * batches are issued in a FIXED order -- hop 1 of batches 0..D-1, then for i = 0, 1, ...: hop 2 of batch i, hop 1 of batch
+    i+D -- so the host has D-1 GPU stages of slack for a batch's hop-2 tokenisation, and so that under torch.distributed every
+    rank issues its collectives in the same order whatever its host timing is;
+  * with W ranks the QUESTIONS are partitioned, not only the index: rank r owns batches r, r+W, r+2W, ...; per hop the ranks'
+    query embeddings are all-gathered, every rank searches all W*B queries in its row shard, the per-shard lists are
+    all-gathered and merged (ShardedIndexFlatIP.search_device), and each rank continues with the rows of its own questions.
+    Per GPU that is 1/W of the encoder forwards and 1/W of the corpus rows; rank 0 collects the records in input order;
+  * `fuse` (--pipeline-batches): hop 2 of batch i and hop 1 of batch i+D run as two concurrent encoder forwards (two lanes /
+    streams) and share ONE corpus pass.
+
+Every question still walks hop-1 encode -> search -> hop-2 inputs -> encode -> search -> path ranking with the same kernels'
+arithmetic; the JSONL of a W-rank run is byte-identical to the one-rank run (tests/test_cli_multirank_gpu.py).
+"""
+import multiprocessing
+import os
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import mhop
+from .data import tokenize_2_11
+from .index import all_gather_dim0
+
+# ------------------------------------------------------------------------------------------------------
+# tokenizer workers
+# ------------------------------------------------------------------------------------------------------
+_WORKER_TOK = None
+
+
+def _worker_init(tokenizer):
+    global _WORKER_TOK
+    _WORKER_TOK = tokenizer
+    os.environ.setdefault("TOKENIZERS_PARALLELISM", "false")  # one batch per worker at a time: parallelism is across workers
+    try:
+        torch.set_num_threads(1)
+    except Exception:
+        pass
+
+
+def _encode_np(tokenizer, texts, pairs, max_lengths):
+    """{max_length: {"input_ids": int64 [n, L], "attention_mask": ...[, "token_type_ids"]}} as numpy (crosses the process boundary)."""
+    out = {}
+    if not (texts if pairs is None else pairs):  # a rank's empty batch (fewer batches than ranks in the last round)
+        return {L: {"input_ids": np.zeros((0, L), np.int64), "attention_mask": np.zeros((0, L), np.int64)} for L in max_lengths}
+    for L in max_lengths:
+        enc = tokenize_2_11(tokenizer, texts, pairs, L)
+        out[L] = {k: np.ascontiguousarray(enc[k].numpy() if torch.is_tensor(enc[k]) else np.asarray(enc[k]), dtype=np.int64)
+                  for k in ("input_ids", "attention_mask", "token_type_ids") if k in enc}
+    return out
+
+
+def _worker_encode(texts, pairs, max_lengths):
+    return _encode_np(_WORKER_TOK, texts, pairs, max_lengths)
+
+
+class _Now:
+    """Future look-alike of an inline call (num_workers = 0)."""
+
+    def __init__(self, fn, *a):
+        self._v = fn(*a)
+
+    def get(self, timeout=None):
+        return self._v
+
+
+class TokenizerPool:
+    """`workers` forked processes that hold the tokenizer; `submit` returns a handle with .get(). MUST be created before the
+    process touches the HIP device (a forked child must not inherit a live runtime); workers = 0 tokenises inline."""
+
+    def __init__(self, tokenizer, workers):
+        self.tokenizer = tokenizer
+        self.workers = max(0, int(workers))
+        self.pool = None
+        self._inline_lock = threading.Lock()  # HF fast tokenizers are not re-entrant ("Already borrowed"): inline calls come from several threads
+        if self.workers > 0:
+            self.pool = multiprocessing.get_context("fork").Pool(self.workers, initializer=_worker_init, initargs=(tokenizer,))
+
+    def submit(self, texts, pairs, max_lengths):
+        if self.pool is None:
+            with self._inline_lock:
+                return _Now(_encode_np, self.tokenizer, texts, pairs, tuple(max_lengths))
+        return self.pool.apply_async(_worker_encode, (texts, pairs, tuple(max_lengths)))
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate()
+            self.pool.join()
+            self.pool = None
+
+
+# ------------------------------------------------------------------------------------------------------
+# the pipeline
+# ------------------------------------------------------------------------------------------------------
+class _Job:
+    __slots__ = ("idx", "lo", "hi", "n", "questions", "ann", "tok1", "tok2", "q_ids", "q_mask", "D", "I", "D_host", "I_host", "e1", "host", "e2",
+                 "result", "q_emb")
+
+    def __init__(self, idx, lo, hi, questions, ann):
+        self.idx, self.lo, self.hi, self.n = idx, lo, hi, hi - lo
+        self.questions, self.ann = questions, ann
+        self.tok1 = self.tok2 = self.q_ids = self.q_mask = self.D = self.I = self.D_host = self.I_host = self.e1 = self.host = self.e2 = None
+        self.result = self.q_emb = None
+
+
+class TwoHopPipeline:
+    """run(questions, ds_items) -> list of per-batch results (this rank's batches; `finish(ann, D, I, D2, I2)` makes one).
+
+    model.encode_q(ids, mask, type_ids[, lane]) -> [n, d]; index.search_device(q, k) -> (D, I) device tensors (IndexFlatIP, or
+    ShardedIndexFlatIP whose search_device runs the exchange); arena = TokenArena for device-side hop-2 assembly or None for the
+    reference's host path (id2doc lookups + pair tokenisation)."""
+
+    def __init__(self, model, index, pool, id2doc, finish, *, batch_size, beam, max_q_len, max_q_sp_len, roberta=True, arena=None,
+                 device=None, rank=0, world=1, group=None, depth=None, fuse=False):
+        self.model, self.index, self.pool, self.id2doc, self.finish = model, index, pool, id2doc, finish
+        self.B, self.beam, self.Lq, self.Lsp, self.roberta = int(batch_size), int(beam), int(max_q_len), int(max_q_sp_len), roberta
+        self.arena = arena
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.cuda = self.device.type == "cuda"
+        self.rank, self.world, self.group = int(rank), int(world), group
+        # in-flight depth: the host path needs slack for the pair tokenisation between the hops; the device path only prefetches
+        self.depth = int(depth) if depth else (2 if arena is not None else 4)
+        self.fuse = bool(fuse)
+        self.d = None
+        self._side = None
+        self._lanes = self._has_lanes(model)
+        self.stats = {"batches": 0, "hop1_forwards": 0, "hop2_forwards": 0, "searches": 0, "queries_searched": 0, "batch_done_t": []}
+
+    @staticmethod
+    def _has_lanes(model):
+        import inspect
+        try:
+            return "lane" in inspect.signature(model.encode_q).parameters
+        except (TypeError, ValueError):
+            return False
+
+    # -- host <-> device plumbing ---------------------------------------------------------------------------
+    def _h2d(self, arr):
+        t = torch.from_numpy(arr)
+        if not self.cuda:
+            return t
+        pin = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)  # torch's caching host allocator: reused, stream-safe
+        pin.copy_(t)
+        return pin.to(self.device, non_blocking=True)
+
+    def _d2h(self, t):
+        if not self.cuda:
+            return t.clone()
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        return host
+
+    def _event(self):
+        if not self.cuda:
+            return None
+        e = torch.cuda.Event()
+        e.record()
+        return e
+
+    def _encode(self, enc, lane=0):
+        ids, mask, tt = enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids")
+        if ids.shape[0] == 0:
+            return torch.zeros((0, self._dim()), dtype=torch.float32, device=self.device)
+        if self._lanes:
+            return self.model.encode_q(ids, mask, tt, lane=lane)
+        return self.model.encode_q(ids, mask, tt)
+
+    def _dim(self):
+        if self.d is None:
+            self.d = int(getattr(self.index, "d"))
+        return self.d
+
+    # -- search: one rank, or all ranks' queries against every shard ---------------------------------------------
+    def _search(self, q, n_pad):
+        """q [n, d]: this rank's queries (n <= n_pad). -> (D, I) [n, beam] of those queries over the WHOLE corpus."""
+        self.stats["searches"] += 1
+        if self.world == 1:
+            self.stats["queries_searched"] += int(q.shape[0])
+            if q.shape[0] == 0:
+                return (torch.zeros((0, self.beam), dtype=torch.float32, device=self.device), torch.zeros((0, self.beam), dtype=torch.int64, device=self.device))
+            return self.index.search_device(q.contiguous(), self.beam)
+        n = int(q.shape[0])
+        qp = q
+        if n < n_pad:  # a fixed block per rank: the collective's shape must not depend on a ragged last batch
+            qp = torch.zeros((n_pad, q.shape[1]), dtype=q.dtype, device=q.device)
+            qp[:n] = q
+        allq = all_gather_dim0(qp.contiguous(), self.world, self.group)
+        self.stats["queries_searched"] += int(allq.shape[0])
+        D, I = self.index.search_device(allq, self.beam)
+        lo = self.rank * n_pad
+        return D[lo:lo + n].contiguous(), I[lo:lo + n].contiguous()
+
+    # -- stages ---------------------------------------------------------------------------------------------------
+    def _tok1(self, job):
+        lens = (self.Lq, self.Lsp) if self.arena is not None and self.Lsp != self.Lq else (self.Lq,)
+        job.tok1 = self.pool.submit(job.questions, None, lens)
+
+    def _hop1_inputs(self, job):
+        enc = job.tok1.get()
+        job.tok1 = None
+        e1 = {k: self._h2d(v) for k, v in enc[self.Lq].items()}
+        if self.arena is not None:
+            # the question without the hop-1 length cap, so that the pair sees the tokens the tokenizer would (eval_mhop_retrieval.py:168)
+            full = enc[self.Lsp] if self.Lsp != self.Lq else enc[self.Lq]
+            job.q_ids, job.q_mask = (e1["input_ids"], e1["attention_mask"]) if self.Lsp == self.Lq else (self._h2d(full["input_ids"]), self._h2d(full["attention_mask"]))
+        return e1
+
+    def _after_hop1(self, job, D, I):
+        job.D, job.I = D, I
+        if self.arena is None:  # host path: the ids go to the host, a thread builds and tokenises the pairs
+            job.D_host, job.I_host = self._d2h(D), self._d2h(I)
+            job.e1 = self._event()
+            job.host = self._threads.submit(self._make_pairs, job)
+
+    def hop1(self, job):
+        q = self._encode(self._hop1_inputs(job))
+        self.stats["hop1_forwards"] += int(job.n > 0)
+        D, I = self._search(q, self.B)
+        self._after_hop1(job, D, I)
+
+    def _make_pairs(self, job):
+        """Worker thread: wait for the hop-1 lists, look the passages up (eval_mhop_retrieval.py:158-166), tokenise the pairs."""
+        if job.e1 is not None:
+            job.e1.synchronize()
+        D, I = job.D_host.numpy(), job.I_host.numpy()
+        if job.n == 0:
+            return None
+        pairs = mhop.build_hop2_pairs(job.questions, D, I, self.id2doc, roberta=self.roberta)  # D gets the -inf of empty passages
+        return self.pool.submit(None, pairs, (self.Lsp,)).get()[self.Lsp]
+
+    def _hop2_inputs(self, job):
+        if self.arena is not None:
+            if job.n == 0:
+                z = torch.zeros((0, self.Lsp), dtype=torch.int64, device=self.device)
+                return {"input_ids": z, "attention_mask": z}
+            ids2, mask2 = self.arena.assemble_hop2(job.q_ids, job.q_mask, job.I, job.D, self.Lsp)  # D: -inf of empty passages, in place
+            job.q_ids = job.q_mask = None
+            return {"input_ids": ids2, "attention_mask": mask2}
+        enc = job.host.result()
+        job.host = None
+        if enc is None:
+            z = torch.zeros((0, self.Lsp), dtype=torch.int64, device=self.device)
+            return {"input_ids": z, "attention_mask": z}
+        return {k: self._h2d(v) for k, v in enc.items()}
+
+    def _after_hop2(self, job, D2, I2):
+        if self.arena is not None:
+            job.D_host, job.I_host = self._d2h(job.D), self._d2h(job.I)
+        d2, i2 = self._d2h(D2), self._d2h(I2)
+        job.D = job.I = None
+        job.e2 = self._event()
+        job.result = self._finisher.submit(self._finish, job, d2, i2)
+
+    def hop2(self, job):
+        q2 = self._encode(self._hop2_inputs(job))
+        self.stats["hop2_forwards"] += int(job.n > 0)
+        D2, I2 = self._search(q2, self.B * self.beam)
+        self._after_hop2(job, D2, I2)
+
+    def hop2_and_hop1(self, job, nxt):
+        """hop 2 of `job` beside hop 1 of `nxt`: two concurrent forwards (two lanes on two streams), ONE corpus pass for both."""
+        enc2 = self._hop2_inputs(job)
+        enc1 = self._hop1_inputs(nxt)
+        if self.cuda and self._lanes:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            start = torch.cuda.Event()
+            start.record()
+            self._side.wait_event(start)
+            with torch.cuda.stream(self._side):
+                q1 = self._encode(enc1, lane=1)
+                done = torch.cuda.Event()
+                done.record()
+            q2 = self._encode(enc2)
+            torch.cuda.current_stream().wait_event(done)
+            q1.record_stream(torch.cuda.current_stream())
+        else:
+            q1 = self._encode(enc1)
+            q2 = self._encode(enc2)
+        self.stats["hop1_forwards"] += int(nxt.n > 0)
+        self.stats["hop2_forwards"] += int(job.n > 0)
+        n2, nb2 = int(q2.shape[0]), self.B * self.beam
+        if self.world == 1:
+            Dc, Ic = self._search(torch.cat([q2, q1], 0), nb2 + self.B)
+            D2, I2, D1, I1 = Dc[:n2], Ic[:n2], Dc[n2:], Ic[n2:]
+        else:  # fixed layout inside this rank's block: hop-2 rows at 0, hop-1 rows at B*beam
+            blk = torch.zeros((nb2 + self.B, q2.shape[1] if n2 else q1.shape[1]), dtype=torch.float32, device=self.device)
+            blk[:n2] = q2
+            blk[nb2:nb2 + q1.shape[0]] = q1
+            Dc, Ic = self._search(blk, nb2 + self.B)
+            D2, I2, D1, I1 = Dc[:n2], Ic[:n2], Dc[nb2:nb2 + q1.shape[0]], Ic[nb2:nb2 + q1.shape[0]]
+        self._after_hop2(job, D2.contiguous(), I2.contiguous())
+        self._after_hop1(nxt, D1.contiguous(), I1.contiguous())
+
+    def _finish(self, job, d2, i2):
+        if job.e2 is not None:
+            job.e2.synchronize()
+        if job.n == 0:
+            return None
+        r = self.finish(job.ann, job.D_host.numpy(), job.I_host.numpy(), d2.numpy(), i2.numpy())
+        self.stats["batch_done_t"].append(time.perf_counter())
+        return r
+
+    # -- the loop ---------------------------------------------------------------------------------------------------
+    def run(self, questions, ds_items):
+        nb = -(-len(questions) // self.B) if questions else 0
+        rounds = -(-nb // self.world) if nb else 0
+        jobs = []
+        for g in range(rounds):
+            b = g * self.world + self.rank
+            lo, hi = min(len(questions), b * self.B), min(len(questions), (b + 1) * self.B)
+            jobs.append(_Job(b, lo, hi, questions[lo:hi], ds_items[lo:hi]))
+        D = max(1, self.depth)
+        ahead = D + 2  # tokenised this many batches before their hop 1 is issued
+        self._threads = ThreadPoolExecutor(max_workers=max(2, D + 1), thread_name_prefix="mdr-host")
+        self._finisher = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mdr-finish")  # one thread: results complete in batch order
+        try:
+            for j in jobs[:ahead]:
+                self._tok1(j)
+            with torch.no_grad():
+                for g in range(min(D, rounds)):
+                    self.hop1(jobs[g])
+                    if g + ahead < rounds:
+                        self._tok1(jobs[g + ahead])
+                for g in range(rounds):
+                    nxt = jobs[g + D] if g + D < rounds else None
+                    if nxt is not None and self.fuse:
+                        self.hop2_and_hop1(jobs[g], nxt)
+                    else:
+                        self.hop2(jobs[g])
+                        if nxt is not None:
+                            self.hop1(nxt)
+                    if g + D + ahead < rounds:
+                        self._tok1(jobs[g + D + ahead])
+                    self.stats["batches"] += int(jobs[g].n > 0)
+            out = []
+            for j in jobs:
+                r = j.result.result()
+                j.result = None
+                if r is not None:
+                    out.append((j.idx, r))
+            return out
+        finally:
+            self._threads.shutdown(wait=True)
+            self._finisher.shutdown(wait=True)
+
+
+def gather_results(per_batch, world, group=None):
+    """[(batch index, result)] of every rank -> on rank 0 the results of ALL batches in input order (others: None)."""
+    if world == 1:
+        return [r for _, r in sorted(per_batch, key=lambda t: t[0])]
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    bucket = [None] * world if rank == 0 else None
+    dist.gather_object(per_batch, bucket, dst=0, group=group)
+    if rank != 0:
+        return None
+    merged = sorted((t for part in bucket for t in part), key=lambda t: t[0])
+    return [r for _, r in merged]

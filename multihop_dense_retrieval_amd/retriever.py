@@ -80,7 +80,10 @@ class _HipRobertaEncoder:
     SURVEY.md §8a row a23)."""
 
     MAX_TOKENS_PER_CALL = 1 << 17  # workspace bound: larger batches are encoded in slices
-    RESIDUAL_FP32_DEFAULT = False
+    # numerics mode of the residual stream (mdr_encoder_config.residual_fp32): 0 = fp16 residual copy (one rounding more per LayerNorm than apex O1),
+    # 1 = fp32 residual stream + fp32 Linear sums, 2 = fp32 residual stream + out-projection / FFN2 outputs rounded to fp16 (literally apex O1's dataflow
+    # around the LayerNorms, the reference's regime: eval_mhop_retrieval.py:86-90). 1 and 2 are the O1-faithful modes; 2 moves 4 bytes per element less.
+    RESIDUAL_FP32_DEFAULT = 2
 
     def __init__(self, config, args=None):
         self.config = config
@@ -93,10 +96,12 @@ class _HipRobertaEncoder:
         self.capture_on_first_use = False
         self.graph_captures = 0
         self.graph_replays = 0
+        self.forward_calls = 0  # encode_seq invocations / sequences encoded (the multi-rank tests assert each rank's share)
+        self.forward_rows = 0
         self.use_graphs = True
-        # apex-O1-faithful fp32 residual stream (mdr_encoder_config.residual_fp32); MDR_RESIDUAL_FP32=0/1 overrides the default for
+        # apex-O1-faithful fp32 residual stream (mdr_encoder_config.residual_fp32); MDR_RESIDUAL_FP32=0/1/2 overrides the default for
         # measurements before the weights are uploaded
-        self.residual_fp32 = bool(int(os.environ.get("MDR_RESIDUAL_FP32", "1" if self.RESIDUAL_FP32_DEFAULT else "0")))
+        self.residual_fp32 = int(os.environ.get("MDR_RESIDUAL_FP32", str(int(self.RESIDUAL_FP32_DEFAULT))))
         self.device = None
         self.training = False
 
@@ -157,6 +162,8 @@ class _HipRobertaEncoder:
         if ids.dim() != 2 or ids.shape != msk.shape:
             raise ValueError(f"input_ids {tuple(ids.shape)} and mask {tuple(msk.shape)} must both be [B, L]")
         B, L = ids.shape
+        self.forward_calls += 1
+        self.forward_rows += int(B)
         if self.use_graphs and 0 < B * L <= self.MAX_TOKENS_PER_CALL and L <= 512:
             return self._encode_graphed(ids, msk, lane)
         out = torch.empty((B, self.config.hidden_size), dtype=torch.float32, device=self.device)

@@ -1,0 +1,261 @@
+"""CPU (-m "not gpu"): the batch pipeline of the drop-in CLI (multihop_dense_retrieval_amd/pipeline.py) against the loop exactly as
+/root/reference/scripts/eval/eval_mhop_retrieval.py:142-206 writes it (one batch at a time, every stage after the previous one),
+with test doubles for the two device operators (a row-wise deterministic "encoder", a brute-force fp64 flat-IP "index") and the
+REAL tokenizer class, worker processes, finisher thread, fixed issue order, question partitioning over ranks (gloo, world 2 and 8)
+and result gathering. What must hold: every batch's (D, I, D', I') and their order are identical to the sequential loop's, for
+every combination of worker count, in-flight depth, --pipeline-batches fusion, device-side / host-side hop-2 inputs and a ragged
+last batch; and each rank encodes only its own share of the batches."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+D_MODEL = 32
+
+
+def make_tokenizer():
+    import transformers
+    bpe = os.path.join(GOLDEN, "tiny_bpe")
+    with open(os.path.join(bpe, "vocab.json")) as f:
+        vocab = json.load(f)
+    with open(os.path.join(bpe, "merges.txt")) as f:
+        merges = [tuple(ln.split()) for ln in f.read().split("\n") if ln and not ln.startswith("#")]
+    return transformers.RobertaTokenizer(vocab=vocab, merges=merges)
+
+
+class ToyEncoder:
+    """Row-wise and deterministic: position-weighted sum of a seeded embedding table over the unmasked tokens (fp64)."""
+
+    def __init__(self, vocab=600, seed=3):
+        g = torch.Generator().manual_seed(seed)
+        self.table = torch.randn((vocab, D_MODEL), generator=g, dtype=torch.float64)
+        self.rows = 0
+        self.calls = 0
+
+    def encode_q(self, ids, mask, type_ids=None):
+        self.calls += 1
+        self.rows += int(ids.shape[0])
+        w = mask.double() * (1.0 + 0.01 * torch.arange(ids.shape[1], dtype=torch.float64))[None, :]
+        return (self.table[ids.clamp(max=self.table.shape[0] - 1)] * w[:, :, None]).sum(1).float()
+
+
+class ToyIndex:
+    """Flat inner-product top-k over `xb` (global ids lo..hi): scores element by element in fp64, so a row's score does not
+    depend on which other rows share its shard; ties to the lowest id. Same surface as IndexFlatIP / its oracle double."""
+
+    def __init__(self, xb, id_offset=0):
+        self.xb, self.d, self.id_offset = torch.as_tensor(xb, dtype=torch.float64), D_MODEL, id_offset
+
+    def reserve(self, n):
+        pass
+
+    def add(self, x):
+        self.xb = torch.cat([self.xb, torch.as_tensor(np.asarray(x), dtype=torch.float64)], 0) if self.xb.numel() else torch.as_tensor(np.asarray(x), dtype=torch.float64)
+
+    def search(self, q, k):
+        q = torch.as_tensor(np.asarray(q) if not torch.is_tensor(q) else q).double()
+        n = self.xb.shape[0]
+        D = torch.full((q.shape[0], k), -torch.finfo(torch.float32).max)
+        I = torch.full((q.shape[0], k), -1, dtype=torch.int64)
+        if n and q.shape[0]:
+            sc = (q[:, None, :] * self.xb[None, :, :]).sum(-1).float()
+            order = torch.argsort(-sc.double() - 0.0, dim=1, stable=True)[:, :k]
+            kk = order.shape[1]
+            D[:, :kk] = torch.gather(sc, 1, order)
+            I[:, :kk] = order + self.id_offset
+        return D, I
+
+    search_device = search
+
+
+def merge_double(Dp, Ip):
+    P, nq, k = Dp.shape
+    D = torch.full((nq, k), -torch.finfo(torch.float32).max)
+    I = torch.full((nq, k), -1, dtype=torch.int64)
+    for q in range(nq):
+        ent = sorted((-float(Dp[p, q, e]), int(Ip[p, q, e])) for p in range(P) for e in range(k) if int(Ip[p, q, e]) >= 0)
+        for j, (s, i) in enumerate(ent[:k]):
+            D[q, j], I[q, j] = -s, i
+    return D, I
+
+
+class ToyArena:
+    """assemble_hop2 of arena.TokenArena in plain torch: `<s> q </s></s> passage </s>` (no truncation needed at these sizes),
+    -inf on the hop-1 score of an empty passage."""
+
+    def __init__(self, id2doc, tok):
+        from multihop_dense_retrieval_amd.data import prefix_space_2_11
+        self.docs, self.empty = [], []
+        for i in range(len(id2doc)):
+            t = id2doc[str(i)]["text"]
+            e = t.strip() == ""
+            self.empty.append(e)
+            self.docs.append(tok(prefix_space_2_11(id2doc[str(i)]["title"] if e else t), add_special_tokens=False)["input_ids"])
+
+    def assemble_hop2(self, q_ids, q_mask, I, D, L):
+        B, beam = I.shape
+        ids = torch.ones((B * beam, L), dtype=torch.int64)
+        mask = torch.zeros_like(ids)
+        for b in range(B):
+            q = q_ids[b][q_mask[b].bool()].tolist()[1:-1]
+            for j in range(beam):
+                doc = int(I[b, j])
+                row = [0] + q + [2, 2] + self.docs[doc] + [2]
+                assert len(row) <= L
+                ids[b * beam + j, :len(row)] = torch.tensor(row)
+                mask[b * beam + j, :len(row)] = 1
+                if self.empty[doc]:
+                    D[b, j] = float("-inf")
+        return ids, mask
+
+
+def make_world(n_docs=83, n_q=47):
+    rng = np.random.default_rng(7)
+    words = ["the", "title", "text", "born", "answer", "question", "and", "row", "den", "pro"]
+    id2doc = {str(i): {"title": f"T{i}", "text": " ".join(rng.choice(words, rng.integers(3, 12)))} for i in range(n_docs)}
+    id2doc["5"]["text"] = "  "
+    items = [{"_id": f"q{i}", "question": " ".join(rng.choice(words, rng.integers(2, 7))) + ("?" if i % 3 else "")} for i in range(n_q)]
+    return id2doc, items
+
+
+def corpus_vectors(id2doc, tok, enc):
+    from multihop_dense_retrieval_amd.data import encode_pairs_2_11
+    rows = []
+    for i in range(len(id2doc)):
+        d = id2doc[str(i)]
+        ids, mask = encode_pairs_2_11(tok, [d["title"]], [d["text"].strip() or d["title"]], 40, True)
+        rows.append(enc.encode_q(torch.tensor(ids), torch.tensor(mask)))
+    xb = torch.cat(rows).double()
+    # the EMPTY passage (5) is the best hop-1 row of question 0, so the title-fallback / -inf rule is on the path
+    from multihop_dense_retrieval_amd import mhop
+    from multihop_dense_retrieval_amd.data import tokenize_2_11
+    e = tokenize_2_11(tok, [mhop.strip_question(make_world()[1][0]["question"])], None, 12)
+    xb[5] = 3.0 * enc.encode_q(e["input_ids"], e["attention_mask"])[0].double()
+    enc.rows = enc.calls = 0
+    return xb.numpy()
+
+
+def reference_loop(tok, enc, index, id2doc, items, B, beam, Lq, Lsp):
+    """The loop as the reference writes it (eval_mhop_retrieval.py:142-206), one stage after the other."""
+    from multihop_dense_retrieval_amd import mhop
+    from multihop_dense_retrieval_amd.data import tokenize_2_11
+    questions = [mhop.strip_question(it["question"]) for it in items]
+    out = []
+    for s in range(0, len(questions), B):
+        bq = questions[s:s + B]
+        e = tokenize_2_11(tok, bq, None, Lq)
+        D, I = index.search(enc.encode_q(e["input_ids"], e["attention_mask"]), beam)
+        D, I = D.numpy().copy(), I.numpy().copy()
+        pairs = mhop.build_hop2_pairs(bq, D, I, id2doc, roberta=True)
+        e2 = tokenize_2_11(tok, None, pairs, Lsp)
+        D2, I2 = index.search(enc.encode_q(e2["input_ids"], e2["attention_mask"]), beam)
+        out.append(([it["_id"] for it in items[s:s + B]], D, I, D2.numpy(), I2.numpy()))
+    return out
+
+
+def finish(ann, D, I, D2, I2):
+    return ([a["_id"] for a in ann], D.copy(), I.copy(), D2.copy(), I2.copy())
+
+
+def same(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x[0] == y[0]
+        for u, v in zip(x[1:], y[1:]):
+            assert np.array_equal(u, v), (x[0][:3], u, v)
+
+
+@pytest.mark.parametrize("workers,depth,fuse,device_hop2", [(0, 1, False, False), (0, 4, False, False), (2, 4, False, False), (2, 2, True, False),
+                                                            (0, 2, False, True), (2, 1, True, True), (2, 3, True, True), (0, 9, True, False)])
+def test_pipeline_equals_the_sequential_loop(workers, depth, fuse, device_hop2):
+    from multihop_dense_retrieval_amd import mhop
+    from multihop_dense_retrieval_amd.pipeline import TokenizerPool, TwoHopPipeline, gather_results
+    tok = make_tokenizer()
+    id2doc, items = make_world()
+    enc = ToyEncoder()
+    index = ToyIndex(corpus_vectors(id2doc, tok, enc))
+    B, beam, Lq, Lsp = 10, 3, 12, 40
+    ref = reference_loop(tok, ToyEncoder(), index, id2doc, items, B, beam, Lq, Lsp)
+    pool = TokenizerPool(tok, workers)
+    try:
+        pipe = TwoHopPipeline(enc, index, pool, id2doc, finish, batch_size=B, beam=beam, max_q_len=Lq, max_q_sp_len=Lsp, roberta=True,
+                              arena=ToyArena(id2doc, tok) if device_hop2 else None, device="cpu", depth=depth, fuse=fuse)
+        got = gather_results(pipe.run([mhop.strip_question(it["question"]) for it in items], items), 1)
+    finally:
+        pool.close()
+    same(got, ref)
+    assert any(np.isinf(r[1]).any() for r in got)  # the empty passage was retrieved somewhere: the -inf rule is exercised
+    assert pipe.stats["batches"] == 5 and pipe.stats["hop1_forwards"] == 5 and pipe.stats["hop2_forwards"] == 5
+    assert pipe.stats["searches"] == (10 if not fuse else 10 - (5 - min(depth, 5)))  # a fused step shares one search
+
+
+def test_pipeline_with_no_questions_and_with_one():
+    from multihop_dense_retrieval_amd.pipeline import TokenizerPool, TwoHopPipeline, gather_results
+    tok = make_tokenizer()
+    id2doc, items = make_world(n_q=1)
+    enc = ToyEncoder()
+    index = ToyIndex(corpus_vectors(id2doc, tok, enc))
+    pool = TokenizerPool(tok, 0)
+    pipe = TwoHopPipeline(enc, index, pool, id2doc, finish, batch_size=10, beam=2, max_q_len=12, max_q_sp_len=40, device="cpu")
+    assert pipe.run([], []) == []
+    got = gather_results(pipe.run(["the title"], items), 1)
+    assert len(got) == 1 and got[0][1].shape == (1, 2) and got[0][3].shape == (2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fuse, device_hop2, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from multihop_dense_retrieval_amd import mhop
+    from multihop_dense_retrieval_amd.index import ShardedIndexFlatIP
+    from multihop_dense_retrieval_amd.pipeline import TokenizerPool, TwoHopPipeline, gather_results
+    tok = make_tokenizer()
+    pool = TokenizerPool(tok, 1 if rank % 2 else 0)  # forked before the process group exists
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    id2doc, items = make_world()
+    enc = ToyEncoder()
+    xb = corpus_vectors(id2doc, tok, enc)
+    sh = ShardedIndexFlatIP(D_MODEL, xb.shape[0], local_index=ToyIndex(np.zeros((0, D_MODEL))), merge_fn=merge_double)
+    sh.local.id_offset = sh.lo
+    sh.add_from_global(xb)
+    B, beam = 10, 3
+    pipe = TwoHopPipeline(enc, sh, pool, id2doc, finish, batch_size=B, beam=beam, max_q_len=12, max_q_sp_len=40, roberta=True,
+                          arena=ToyArena(id2doc, tok) if device_hop2 else None, device="cpu", rank=rank, world=world, depth=2, fuse=fuse)
+    mine = pipe.run([mhop.strip_question(it["question"]) for it in items], items)
+    pool.close()
+    allr = gather_results(mine, world)
+    nb = -(-len(items) // B)
+    my_batches = len(range(rank, nb, world))
+    assert pipe.stats["batches"] == my_batches and enc.calls == 2 * my_batches, (rank, pipe.stats, enc.calls)  # 1/W of the encoder forwards
+    assert (allr is None) == (rank != 0)
+    if rank == 0:
+        ref = reference_loop(tok, ToyEncoder(), ToyIndex(xb), id2doc, items, B, beam, 12, 40)
+        same(allr, ref)
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fuse,device_hop2", [(2, False, False), (2, True, True), (8, False, True), (8, True, False)])
+def test_question_partitioned_ranks_reproduce_the_one_rank_run(tmp_path, world, fuse, device_hop2):
+    """47 questions in batches of 10 = 5 batches: with 8 ranks three of them own NO batch (they still take part in every
+    collective), with 2 ranks one owns 3 and one 2; the last batch is ragged."""
+    mp.spawn(_worker, args=(world, _free_port(), fuse, device_hop2, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "ok").exists()
