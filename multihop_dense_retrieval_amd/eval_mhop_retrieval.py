@@ -222,10 +222,20 @@ def _run(args, tokenizer, pool, world, rank):
     logger.info("Encoding questions and searching")
     questions = [mhop.strip_question(it["question"]) for it in ds_items]
 
+    class _Memo(dict):
+        """Per-batch view of id2doc: a passage is looked up (corpus store: decoded from the map) once, however many chains name it."""
+
+        def __missing__(self, key):
+            v = self[key] = corpus[key]
+            return v
+
+    corpus = id2doc
+
     def finish_batch(batch_ann, D, I, D_, I_):
         """Path ranking, metrics and output records of one batch (eval_mhop_retrieval.py:181-258); runs on the finisher thread."""
         chains = mhop.rank_paths(D, I, D_, I_, args.beam_size, args.topk)
         ms, recs = [], []
+        id2doc = _Memo()
         for ann, ch in zip(batch_ann, chains):
             if args.only_eval_ans:  # answer-string recall over the retrieved chains; nothing is saved (:208-217)
                 ms.append(answer_recall.answer_metrics(ann, ch, id2doc))

@@ -25,6 +25,7 @@ arithmetic; the JSONL of a W-rank run is byte-identical to the one-rank run (tes
 """
 import multiprocessing
 import os
+import sys
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -33,7 +34,7 @@ import numpy as np
 import torch
 
 from . import mhop
-from .data import tokenize_2_11
+from .data import is_roberta_family, roberta_single_np, tokenize_2_11
 from .index import all_gather_dim0
 
 # ------------------------------------------------------------------------------------------------------
@@ -54,9 +55,11 @@ def _worker_init(tokenizer):
 
 def _encode_np(tokenizer, texts, pairs, max_lengths):
     """{max_length: {"input_ids": int64 [n, L], "attention_mask": ...[, "token_type_ids"]}} as numpy (crosses the process boundary)."""
-    out = {}
     if not (texts if pairs is None else pairs):  # a rank's empty batch (fewer batches than ranks in the last round)
         return {L: {"input_ids": np.zeros((0, L), np.int64), "attention_mask": np.zeros((0, L), np.int64)} for L in max_lengths}
+    if is_roberta_family(tokenizer) and pairs is None:  # one BPE pass serves every length (hop-1 cap and the uncapped question of the device path)
+        return {L: {"input_ids": i, "attention_mask": m} for L, (i, m) in roberta_single_np(tokenizer, list(texts), max_lengths).items()}
+    out = {}
     for L in max_lengths:
         enc = tokenize_2_11(tokenizer, texts, pairs, L)
         out[L] = {k: np.ascontiguousarray(enc[k].numpy() if torch.is_tensor(enc[k]) else np.asarray(enc[k]), dtype=np.int64)
@@ -133,12 +136,13 @@ class TwoHopPipeline:
         self.cuda = self.device.type == "cuda"
         self.rank, self.world, self.group = int(rank), int(world), group
         # in-flight depth: the host path needs slack for the pair tokenisation between the hops; the device path only prefetches
-        self.depth = int(depth) if depth else (2 if arena is not None else 4)
+        self.depth = int(depth) if depth else (2 if arena is not None else 8)
         self.fuse = bool(fuse)
         self.d = None
         self._side = None
         self._lanes = self._has_lanes(model)
-        self.stats = {"batches": 0, "hop1_forwards": 0, "hop2_forwards": 0, "searches": 0, "queries_searched": 0, "batch_done_t": []}
+        self.stats = {"batches": 0, "hop1_forwards": 0, "hop2_forwards": 0, "searches": 0, "queries_searched": 0, "batch_done_t": [],
+                      "wait_tok1_s": 0.0, "wait_tok2_s": 0.0, "finish_busy_s": 0.0, "drain_s": 0.0}
 
     @staticmethod
     def _has_lanes(model):
@@ -210,7 +214,9 @@ class TwoHopPipeline:
         job.tok1 = self.pool.submit(job.questions, None, lens)
 
     def _hop1_inputs(self, job):
+        t0 = time.perf_counter()
         enc = job.tok1.get()
+        self.stats["wait_tok1_s"] += time.perf_counter() - t0
         job.tok1 = None
         e1 = {k: self._h2d(v) for k, v in enc[self.Lq].items()}
         if self.arena is not None:
@@ -250,7 +256,9 @@ class TwoHopPipeline:
             ids2, mask2 = self.arena.assemble_hop2(job.q_ids, job.q_mask, job.I, job.D, self.Lsp)  # D: -inf of empty passages, in place
             job.q_ids = job.q_mask = None
             return {"input_ids": ids2, "attention_mask": mask2}
+        t0 = time.perf_counter()
         enc = job.host.result()
+        self.stats["wait_tok2_s"] += time.perf_counter() - t0
         job.host = None
         if enc is None:
             z = torch.zeros((0, self.Lsp), dtype=torch.int64, device=self.device)
@@ -311,7 +319,9 @@ class TwoHopPipeline:
             job.e2.synchronize()
         if job.n == 0:
             return None
+        t0 = time.perf_counter()
         r = self.finish(job.ann, job.D_host.numpy(), job.I_host.numpy(), d2.numpy(), i2.numpy())
+        self.stats["finish_busy_s"] += time.perf_counter() - t0
         self.stats["batch_done_t"].append(time.perf_counter())
         return r
 
@@ -325,9 +335,13 @@ class TwoHopPipeline:
             lo, hi = min(len(questions), b * self.B), min(len(questions), (b + 1) * self.B)
             jobs.append(_Job(b, lo, hi, questions[lo:hi], ds_items[lo:hi]))
         D = max(1, self.depth)
-        ahead = D + 2  # tokenised this many batches before their hop 1 is issued
+        ahead = D + max(2, min(16, 2 * getattr(self.pool, "workers", 0)))  # tokenised this many batches before their hop 1 is issued
         self._threads = ThreadPoolExecutor(max_workers=max(2, D + 1), thread_name_prefix="mdr-host")
         self._finisher = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mdr-finish")  # one thread: results complete in batch order
+        # the issuing thread shares the GIL with the finisher and the pair builders: with CPython's default 5 ms switch interval every launch
+        # it makes while one of them computes waits up to 5 ms for the lock -- most of a batch's GPU time
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(2e-4)
         try:
             for j in jobs[:ahead]:
                 self._tok1(j)
@@ -348,13 +362,16 @@ class TwoHopPipeline:
                         self._tok1(jobs[g + D + ahead])
                     self.stats["batches"] += int(jobs[g].n > 0)
             out = []
+            t0 = time.perf_counter()
             for j in jobs:
                 r = j.result.result()
                 j.result = None
                 if r is not None:
                     out.append((j.idx, r))
+            self.stats["drain_s"] = time.perf_counter() - t0  # issuing done -> last batch finished on the host
             return out
         finally:
+            sys.setswitchinterval(old_switch)
             self._threads.shutdown(wait=True)
             self._finisher.shutdown(wait=True)
 

@@ -262,3 +262,27 @@ def test_device_assembly_equals_the_hf_pair_encoding(tok, n, beam):
     assert torch.equal(ids.cpu(), enc["input_ids"])
     assert torch.equal(mask.cpu(), enc["attention_mask"])
     assert np.array_equal(Dd.cpu().numpy(), Dh)  # -inf exactly where the host rule puts it
+
+
+def test_token_ids_equal_transformers_2_11_when_the_golden_file_exists():
+    """scripts/parity_with_assets.sh (run where transformers==2.11.0 and the roberta-base files exist) leaves tests/golden/tokenizer_2_11.json: the
+    reference pin's own token ids for its three tokenisation call sites. With that file and MDR_ROBERTA_DIR (a local roberta-base directory) present,
+    this build's restatement must reproduce them token for token; without them the fidelity stays UNPINNED and the test says so by skipping."""
+    import json
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tokenizer_2_11.json")
+    roberta = os.environ.get("MDR_ROBERTA_DIR", "")
+    if not os.path.exists(gold) or not os.path.isdir(roberta):
+        pytest.skip("no transformers-2.11 golden token ids / roberta-base files here (scripts/parity_with_assets.sh produces them)")
+    import transformers
+    from multihop_dense_retrieval_amd.data import encode_pairs_2_11, tokenize_2_11
+    g = json.load(open(gold))
+    tok = transformers.AutoTokenizer.from_pretrained(roberta)
+    e = tokenize_2_11(tok, g["questions"], None, 70)
+    assert np.array_equal(np.asarray(e["input_ids"]), np.asarray(g["hop1"]["input_ids"]))
+    pairs = [(g["questions"][i], g["docs"][i]["text"] if g["docs"][i]["text"].strip() else g["docs"][i]["title"]) for i in range(200)]
+    for L, key in ((350, "hop2"), (351, "hop2_odd")):
+        e = tokenize_2_11(tok, None, pairs, L)
+        assert np.array_equal(np.asarray(e["input_ids"]), np.asarray(g[key]["input_ids"])), key
+    ids, _ = encode_pairs_2_11(tok, [d["title"].strip() for d in g["docs"]], [(d["text"].strip() or d["title"]) for d in g["docs"]], 300, False)
+    assert ids == g["ctx"]
