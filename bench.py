@@ -109,7 +109,7 @@ def parse():
                          "cli: queries/s of the drop-in CLI itself (scripts/eval/eval_mhop_retrieval.py main()) on synthetic assets of the headline's size")
     ap.add_argument("--questions", type=int, default=7405, help="--mode cli: questions in the synthetic qas file (HotpotQA dev has 7405)")
     ap.add_argument("--cli-dir", default=None, help="--mode cli: where the synthetic assets go (default: /dev/shm when it has room, else /tmp); removed afterwards")
-    ap.add_argument("--cli-workers", type=int, default=10, help="--mode cli: the CLI's --num-workers (tokenizer worker processes; the reference's default is 10)")
+    ap.add_argument("--cli-workers", type=int, default=16, help="--mode cli: the CLI's --num-workers (tokenizer worker processes; the flag's default is the reference's 10)")
     ap.add_argument("--cli-legs", default="default,device", help="--mode cli: which flag sets to run: default = the reference's flags, device = --hop2-on-device --pipeline-batches")
     ap.add_argument("--pool", type=int, default=16,
                     help="DIFFERENT question batches the timed steps cycle through (different lengths -> different hop-1 answers -> 19-22 k hop-2 tokens per batch "

@@ -127,6 +127,8 @@ class TwoHopPipeline:
     ShardedIndexFlatIP whose search_device runs the exchange); arena = TokenArena for device-side hop-2 assembly or None for the
     reference's host path (id2doc lookups + pair tokenisation)."""
 
+    PAIR_CHUNK = 25  # (question, passage) pairs per tokenizer task
+
     def __init__(self, model, index, pool, id2doc, finish, *, batch_size, beam, max_q_len, max_q_sp_len, roberta=True, arena=None,
                  device=None, rank=0, world=1, group=None, depth=None, fuse=False):
         self.model, self.index, self.pool, self.id2doc, self.finish = model, index, pool, id2doc, finish
@@ -142,7 +144,9 @@ class TwoHopPipeline:
         self._side = None
         self._lanes = self._has_lanes(model)
         self.stats = {"batches": 0, "hop1_forwards": 0, "hop2_forwards": 0, "searches": 0, "queries_searched": 0, "batch_done_t": [],
-                      "wait_tok1_s": 0.0, "wait_tok2_s": 0.0, "finish_busy_s": 0.0, "drain_s": 0.0}
+                      "wait_tok1_s": 0.0, "wait_tok2_s": 0.0, "finish_busy_s": 0.0, "drain_s": 0.0, "main_s": {}, "gpu_stage_ms": None}
+        self._stage_ev = []
+        self._h2d_ring, self._d2h_free, self._d2h_lock = {}, {}, threading.Lock()
 
     @staticmethod
     def _has_lanes(model):
@@ -153,25 +157,58 @@ class TwoHopPipeline:
             return False
 
     # -- host <-> device plumbing ---------------------------------------------------------------------------
+    # Pinned staging buffers are allocated ONCE per (shape, dtype) and recycled: a fresh `torch.empty(pin_memory=True)` per transfer cost
+    # 2-3 ms each on the MI355X boxes (hipHostMalloc; measured: 10 ms of a 13.7 ms batch went there), more than a batch's tokenisation.
     def _h2d(self, arr):
         t = torch.from_numpy(arr)
         if not self.cuda:
             return t
-        pin = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)  # torch's caching host allocator: reused, stream-safe
-        pin.copy_(t)
-        return pin.to(self.device, non_blocking=True)
+        key = (tuple(t.shape), t.dtype)
+        ring = self._h2d_ring.setdefault(key, [])
+        slot = None
+        for cand in ring:  # a buffer whose previous copy has left the host
+            if cand[1].query():
+                slot = cand
+                break
+        if slot is None:
+            if len(ring) >= 16:
+                slot = ring[0]
+                slot[1].synchronize()
+            else:
+                slot = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True), None]
+                ring.append(slot)
+        slot[0].copy_(t)
+        dev = slot[0].to(self.device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        ring.append(ring.pop(ring.index(slot)))  # least recently used first
+        return dev
 
     def _d2h(self, t):
+        """Device tensor -> pinned host tensor (async; valid behind the stage's event). The buffer returns to the pool in _finish."""
         if not self.cuda:
             return t.clone()
-        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        key = (tuple(t.shape), t.dtype)
+        with self._d2h_lock:
+            free = self._d2h_free.setdefault(key, [])
+            host = free.pop() if free else None
+        if host is None:
+            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         host.copy_(t, non_blocking=True)
         return host
+
+    def _release(self, *hosts):
+        if not self.cuda:
+            return
+        with self._d2h_lock:
+            for h in hosts:
+                if h is not None:
+                    self._d2h_free.setdefault((tuple(h.shape), h.dtype), []).append(h)
 
     def _event(self):
         if not self.cuda:
             return None
-        e = torch.cuda.Event()
+        e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
 
@@ -233,10 +270,16 @@ class TwoHopPipeline:
             job.host = self._threads.submit(self._make_pairs, job)
 
     def hop1(self, job):
-        q = self._encode(self._hop1_inputs(job))
+        t = time.perf_counter()
+        enc = self._hop1_inputs(job)
+        t = self._tick("hop1_inputs", t)
+        q = self._encode(enc)
+        t = self._tick("encode_issue", t)
         self.stats["hop1_forwards"] += int(job.n > 0)
         D, I = self._search(q, self.B)
+        t = self._tick("search_issue", t)
         self._after_hop1(job, D, I)
+        self._tick("after", t)
 
     def _make_pairs(self, job):
         """Worker thread: wait for the hop-1 lists, look the passages up (eval_mhop_retrieval.py:158-166), tokenise the pairs."""
@@ -246,7 +289,11 @@ class TwoHopPipeline:
         if job.n == 0:
             return None
         pairs = mhop.build_hop2_pairs(job.questions, D, I, self.id2doc, roberta=self.roberta)  # D gets the -inf of empty passages
-        return self.pool.submit(None, pairs, (self.Lsp,)).get()[self.Lsp]
+        # a batch's pairs go to the workers in pieces: its tokenisation latency (what the in-flight depth has to cover) shrinks with the piece
+        step = self.PAIR_CHUNK if getattr(self.pool, "workers", 0) > 1 else len(pairs)
+        parts = [self.pool.submit(None, pairs[lo:lo + step], (self.Lsp,)) for lo in range(0, len(pairs), step)]
+        parts = [p.get()[self.Lsp] for p in parts]
+        return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
 
     def _hop2_inputs(self, job):
         if self.arena is not None:
@@ -274,15 +321,34 @@ class TwoHopPipeline:
         job.result = self._finisher.submit(self._finish, job, d2, i2)
 
     def hop2(self, job):
-        q2 = self._encode(self._hop2_inputs(job))
+        t = time.perf_counter()
+        ev0 = self._event()
+        enc = self._hop2_inputs(job)
+        t = self._tick("hop2_inputs", t)
+        q2 = self._encode(enc)
+        t = self._tick("encode_issue", t)
         self.stats["hop2_forwards"] += int(job.n > 0)
         D2, I2 = self._search(q2, self.B * self.beam)
+        t = self._tick("search_issue", t)
         self._after_hop2(job, D2, I2)
+        self._tick("after", t)
+        if ev0 is not None:
+            self._stage_ev.append((ev0, job.e2))
+
+    def _tick(self, name, t0):
+        """Main-thread seconds per section of a stage (stats["main_s"]): where the issuing thread's time goes."""
+        t1 = time.perf_counter()
+        self.stats["main_s"][name] = self.stats["main_s"].get(name, 0.0) + (t1 - t0)
+        return t1
 
     def hop2_and_hop1(self, job, nxt):
         """hop 2 of `job` beside hop 1 of `nxt`: two concurrent forwards (two lanes on two streams), ONE corpus pass for both."""
+        t = time.perf_counter()
+        ev0 = self._event()
         enc2 = self._hop2_inputs(job)
+        t = self._tick("hop2_inputs", t)
         enc1 = self._hop1_inputs(nxt)
+        t = self._tick("hop1_inputs", t)
         if self.cuda and self._lanes:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
@@ -299,6 +365,7 @@ class TwoHopPipeline:
         else:
             q1 = self._encode(enc1)
             q2 = self._encode(enc2)
+        t = self._tick("encode_issue", t)
         self.stats["hop1_forwards"] += int(nxt.n > 0)
         self.stats["hop2_forwards"] += int(job.n > 0)
         n2, nb2 = int(q2.shape[0]), self.B * self.beam
@@ -311,18 +378,24 @@ class TwoHopPipeline:
             blk[nb2:nb2 + q1.shape[0]] = q1
             Dc, Ic = self._search(blk, nb2 + self.B)
             D2, I2, D1, I1 = Dc[:n2], Ic[:n2], Dc[nb2:nb2 + q1.shape[0]], Ic[nb2:nb2 + q1.shape[0]]
+        t = self._tick("search_issue", t)
         self._after_hop2(job, D2.contiguous(), I2.contiguous())
         self._after_hop1(nxt, D1.contiguous(), I1.contiguous())
+        t = self._tick("after", t)
+        if ev0 is not None:
+            self._stage_ev.append((ev0, job.e2))
 
     def _finish(self, job, d2, i2):
         if job.e2 is not None:
             job.e2.synchronize()
-        if job.n == 0:
-            return None
-        t0 = time.perf_counter()
-        r = self.finish(job.ann, job.D_host.numpy(), job.I_host.numpy(), d2.numpy(), i2.numpy())
-        self.stats["finish_busy_s"] += time.perf_counter() - t0
-        self.stats["batch_done_t"].append(time.perf_counter())
+        r = None
+        if job.n > 0:
+            t0 = time.perf_counter()
+            r = self.finish(job.ann, job.D_host.numpy(), job.I_host.numpy(), d2.numpy(), i2.numpy())  # (finish must not keep views of its inputs)
+            self.stats["finish_busy_s"] += time.perf_counter() - t0
+            self.stats["batch_done_t"].append(time.perf_counter())
+        self._release(job.D_host, job.I_host, d2, i2)
+        job.D_host = job.I_host = None
         return r
 
     # -- the loop ---------------------------------------------------------------------------------------------------
@@ -369,6 +442,9 @@ class TwoHopPipeline:
                 if r is not None:
                     out.append((j.idx, r))
             self.stats["drain_s"] = time.perf_counter() - t0  # issuing done -> last batch finished on the host
+            if self._stage_ev:  # device time of the hop-2 stages (issue of the stage's first op -> its last D2H done), steady state: median
+                ms = sorted(a.elapsed_time(b) for a, b in self._stage_ev)
+                self.stats["gpu_stage_ms"] = {"median": round(ms[len(ms) // 2], 3), "min": round(ms[0], 3), "max": round(ms[-1], 3)}
             return out
         finally:
             sys.setswitchinterval(old_switch)
