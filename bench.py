@@ -99,6 +99,9 @@ def parse():
     ap.add_argument("--sequential", action="store_true",
                     help="one batch at a time (hop-1 encode, search, hop-2 encode, search as four dependent stages). Default: the "
                          "software-pipelined loop -- hop 2 of batch i beside hop 1 of batch i+1: two concurrent encoder forwards (two lanes / streams) + one fused corpus pass")
+    ap.add_argument("--loop", choices=["deep", "pipelined"], default="deep",
+                    help="deep (default): two batches in flight -- the corpus pass of step i (hop 2 of batch i + hop 1 of batch i+2) on its own stream beside the "
+                         "encoder forwards of step i+1; pipelined: round 2-3's loop (hop 2 of batch i beside hop 1 of batch i+1, then their corpus pass)")
     ap.add_argument("--no-sequential", action="store_true", help="pipelined run: do not append the sequential sub-result")
     ap.add_argument("--no-anisotropic", action="store_true", help="do not append the anisotropic-corpus MIPS sub-result (N = 1, beam 1)")
     ap.add_argument("--aniso-m", type=float, nargs="*", default=[20.0, 200.0], help="norms m of the common component of the anisotropic sub-result")
@@ -492,7 +495,7 @@ def cli_mode(args):
     if world == 1 and not args.no_sequential:
         sidx, local, lo, hi, GB, planted, rows_sum = build_pipeline(args, 1, 0, device, None, False)
         pipe = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len, max_q_sp_len=args.max_q_sp_len,
-                                    use_encoder=True, planted_rows=rows_sum, pipelined=True, pool=args.pool)
+                                    use_encoder=True, planted_rows=rows_sum, pipelined=2 if args.loop == "deep" else True, pool=args.pool)
         _, el = timed_steps(pipe, args, 1, device, None)
         result["device_loop"] = {"value": round(B * args.steps / el, 2), "unit": "queries/s", "ms_per_step": round(el / args.steps * 1e3, 4),
                                  "note": "bench.py default mode (device-resident synthetic loop, software-pipelined), same box, same process"}
@@ -591,7 +594,7 @@ def main():
     pipe = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device,
                                 max_q_len=args.max_q_len, max_q_sp_len=args.max_q_sp_len,
                                 use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank, world=world, weak=weak,
-                                pipelined=not args.sequential, pool=args.pool)
+                                pipelined=False if args.sequential else (2 if args.loop == "deep" else True), pool=args.pool)
     out, elapsed = timed_steps(pipe, args, world, device, dist)
 
     # self-checks, outside the timed region: structural properties + exactness against a brute-force pass over ALL rows
@@ -624,8 +627,11 @@ def main():
                                f"{' , MIPS-only (no encoder)' if not pipe.use_encoder else ', RoBERTa-base encoder (random init)'}",
                    "rows": N, "dim": d, "batch": B, "global_batch": GB, "beam": args.beam, "topk": args.topk, "shards": world,
                    "encoder": pipe.encoder_desc(), "index_build_s": round(build_s, 2),
-                   "loop": ("software-pipelined: hop 2 of batch i beside hop 1 of batch i+1 = two concurrent encoder forwards (two lanes / streams) + one fused "
-                            "corpus pass (every batch still walks the full hop-1 -> hop-2 chain; see `sequential` for the unpipelined loop)") if pipe.pipelined
+                   "loop": ("software-pipelined, two batches deep: hop 2 of batch i beside hop 1 of batch i+2 (two concurrent encoder forwards, two lanes / streams), "
+                            "their ONE fused corpus pass on a third stream beside the encoder forwards of step i+1, path ranking behind it (every batch still walks "
+                            "the full hop-1 -> hop-2 chain; see `sequential` for the unpipelined loop, `pipelined_one_deep` for round 3's)") if getattr(pipe, "deep", False)
+                           else ("software-pipelined: hop 2 of batch i beside hop 1 of batch i+1 = two concurrent encoder forwards (two lanes / streams) + one fused "
+                                 "corpus pass (every batch still walks the full hop-1 -> hop-2 chain; see `sequential` for the unpipelined loop)") if pipe.pipelined
                            else "sequential: one batch at a time, four dependent stages"},
         "roofline": roofline,
         "self_check": ok,
@@ -693,6 +699,19 @@ def main():
     result["stage_share"] = {"encoder": round((stage.get("hop1_encode", 0) + stage.get("hop2_encode", 0)) / ms_per_step, 3),
                              "mips": round((stage.get("hop1_search", 0) + stage.get("hop2_search", 0)) / ms_per_step, 3)}
 
+    if getattr(pipe, "deep", False) and not args.no_sequential:
+        # round 2-3's loop (one batch deep: the corpus pass between the encoder stages) on the same index, encoder and arena: sub-result of the same line
+        mhop.SyntheticTwoHop._defer_encoder = True
+        pipe_1 = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
+                                      max_q_sp_len=args.max_q_sp_len, use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank,
+                                      world=world, weak=weak, pipelined=True, pool=args.pool)
+        mhop.SyntheticTwoHop._defer_encoder = False
+        if pipe.use_encoder:
+            pipe_1.encoder, pipe_1.arena = pipe.encoder, pipe.arena
+        _, el_1 = timed_steps(pipe_1, args, world, device, dist)
+        result["pipelined_one_deep"] = {"value": round(GB * args.steps / el_1, 2), "unit": "queries/s", "ms_per_step": round(el_1 / args.steps * 1e3, 4),
+                                        "stage_ms": pipe_1.stage_ms(), "mips_roofline": mips_roofline(pipe_1, local, args, d)}
+        del pipe_1
     if pipe.pipelined and not args.no_sequential:
         # the same job, one batch at a time (the loop exactly as the reference writes it): sub-result of the same line
         mhop.SyntheticTwoHop._defer_encoder = True  # share the encoder and the arena of the main pipeline
@@ -731,8 +750,8 @@ def main():
             assert int(enc_m.residual_fp32) == mode
             mhop.SyntheticTwoHop._defer_encoder = True
             pipe_r = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
-                                          max_q_sp_len=args.max_q_sp_len, use_encoder=True, planted_rows=rows_sum, rank=rank, world=world, weak=weak, pipelined=True,
-                                          pool=args.pool)
+                                          max_q_sp_len=args.max_q_sp_len, use_encoder=True, planted_rows=rows_sum, rank=rank, world=world, weak=weak,
+                                          pipelined=2 if pipe.deep else True, pool=args.pool)
             mhop.SyntheticTwoHop._defer_encoder = False
             pipe_r.encoder, pipe_r.arena = enc_m, pipe.arena
             out_r, el_r = timed_steps(pipe_r, args, world, device, dist)

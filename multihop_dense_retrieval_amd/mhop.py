@@ -141,8 +141,11 @@ class SyntheticTwoHop:
         self.Lq, self.Lsp = max_q_len, max_q_sp_len
         self.use_encoder = use_encoder
         self.pipelined = bool(pipelined)
+        self.deep = pipelined == 2 or pipelined == "deep"  # two batches deep: the corpus pass on its own stream beside the next step's encoders
         self._carry = None  # pipelined mode: (q, D, I) of the batch whose hop 1 is already done
+        self._deep = collections.deque()  # deep mode: (q, D, I, event) of the two batches whose hop 1 is done or in flight
         self._side = None   # side stream of the pipelined loop
+        self._search_stream = None
         self.rank, self.world = rank, world
         self.weak = bool(weak) and world > 1
         self.local = getattr(index, "local", index)
@@ -322,7 +325,98 @@ class SyntheticTwoHop:
         self._cur = (self._cur + 1) % self.pool
         return {"q": q, "q2": q2, "D": D, "I": I, "D2": D2, "I2": I2, "hop1": h1, "hop2": h2, "score": sc, "ids2": ids, "mask2": mask}
 
+    # -- two batches deep: the corpus pass overlaps the next step's encoder forwards ---------------------------------
+    def _hop1_of(self, ent):
+        b = self.batches[ent]
+        if self.use_encoder:
+            q = self._encode(b["q_ids"], b["q_mask"])
+        else:
+            q = self.planted_rows + b["noise"]
+            if self.weak:
+                from .index import all_gather_dim0
+                q = all_gather_dim0(q, self.world)
+        D, I = self._search(q, self.beam)
+        if self.weak:
+            q, D, I = self._own(q), self._own(D).contiguous(), self._own(I).contiguous()
+        return q, D, I
+
+    def _step_deep(self):
+        """_step_pipelined one batch deeper. There the corpus pass of a step (hop 2 of batch i + hop 1 of batch i+1) stands between the
+        step's encoder forwards and the next step's, which need its hop-1 lists: an HBM-bound kernel and an MFMA/L2-bound stage run one
+        after the other. Here the pass of step i carries hop 1 of batch i+2, so nothing in step i+1 depends on it: it runs on its OWN
+        stream beside the encoder forwards of step i+1 (which wait for the pass of step i-1), and the path ranking of batch i rides behind
+        it. Per step every batch still gets one hop-1 forward, one hop-2 forward and its share of one fused corpus pass; only the order
+        in which independent batches occupy the GPU changes."""
+        B, bm = self.B, self.beam
+        if self._search_stream is None:
+            self._search_stream = torch.cuda.Stream(device=self.device)
+            self._side = torch.cuda.Stream(device=self.device)
+        main, side, ss = torch.cuda.current_stream(), self._side, self._search_stream
+        if not self._deep:  # prologue: hop 1 of the first two batches, plainly
+            for k in range(2):
+                q, D, I = self._hop1_of((self._cur + k) % self.pool)
+                e = torch.cuda.Event()
+                e.record()
+                self._deep.append((q, D, I, e))
+            self._search_ev = []
+        q, D, I, ready = self._deep.popleft()
+        main.wait_event(ready)  # the pass that carried this batch's hop 1 (issued two steps ago)
+        for t in (q, D, I):
+            t.record_stream(main)
+        ev = [self._mark()]
+        ev.append(ev[0])
+        ev.append(ev[0])
+        nb = self.batches[(self._cur + 2) % self.pool]
+        if self.use_encoder:
+            start = torch.cuda.Event()
+            start.record()
+            side.wait_event(start)
+            with torch.cuda.stream(side):
+                q_next = self._encode(nb["q_ids"], nb["q_mask"], lane=1)
+                done = torch.cuda.Event()
+                done.record()
+            ids, mask = self._hop2_inputs(I, D)
+            ev.append(self._mark())
+            q2 = self._encode(ids, mask)
+        else:
+            ids = mask = None
+            ev.append(self._mark())
+            q2 = (0.5 * q).repeat_interleave(bm, 0) + self.table[(I.reshape(-1) % 1024)]
+            q_next = self.planted_rows + nb["noise"]
+            if self.weak:
+                from .index import all_gather_dim0
+                q2, q_next = all_gather_dim0(q2.contiguous(), self.world), all_gather_dim0(q_next, self.world)
+            done = None
+        ev.append(self._mark())
+        enc_done = torch.cuda.Event()
+        enc_done.record()
+        ss.wait_event(enc_done)
+        if done is not None:
+            ss.wait_event(done)
+        with torch.cuda.stream(ss):
+            for t in (q2, q_next, D, I):
+                t.record_stream(ss)
+            e = torch.cat([q2, q_next], 0) if not self.weak else self._interleave(q2, q_next)
+            Dc, Ic = self._search(e.contiguous(), bm)
+            if self.weak:
+                e, Dc, Ic = self._own(e), self._own(Dc), self._own(Ic)
+            q2o, qn = e[:B * bm], e[B * bm:]
+            D2, I2 = Dc[:B * bm].contiguous(), Ic[:B * bm].contiguous()
+            Dn, In = Dc[B * bm:].contiguous(), Ic[B * bm:].contiguous()
+            ev.append(self._mark())
+            h1, h2, sc = rank_paths_device(D, I, D2, I2, bm, self.topk)
+            ev.append(self._mark())
+            fin = torch.cuda.Event()
+            fin.record()
+        self._deep.append((qn, Dn, In, fin))
+        self._ev.append(ev)  # (stages overlap across steps here: hop2_search / rank_paths run beside the NEXT step's encoder stage)
+        self.step_log.append((self._cur, mask.sum(1) if mask is not None else None))
+        self._cur = (self._cur + 1) % self.pool
+        return {"q": q, "q2": q2o, "D": D, "I": I, "D2": D2, "I2": I2, "hop1": h1, "hop2": h2, "score": sc, "ids2": ids, "mask2": mask}
+
     def step(self):
+        if self.deep:
+            return self._step_deep()
         if self.pipelined:
             return self._step_pipelined()
         ev = [self._mark()]

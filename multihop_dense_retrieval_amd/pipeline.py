@@ -181,7 +181,10 @@ class TwoHopPipeline:
         dev = slot[0].to(self.device, non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record()
-        ring.append(ring.pop(ring.index(slot)))  # least recently used first
+        for i, cand in enumerate(ring):  # least recently used first (identity, not ==: the slots hold tensors)
+            if cand is slot:
+                ring.append(ring.pop(i))
+                break
         return dev
 
     def _d2h(self, t):
