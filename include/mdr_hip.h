@@ -74,7 +74,14 @@ int mdr_index_free(mdr_index* h);
 int mdr_index_reserve(mdr_index* h, int64_t n_rows);
 
 /* Append n rows of `d` elements (C-contiguous, element type src_dtype) from a host or device buffer.
- * Rows receive consecutive ids starting at mdr_index_ntotal(). (IndexFlatIP.add) */
+ * Rows receive consecutive ids starting at mdr_index_ntotal(). (IndexFlatIP.add)
+ * A rejected call (MDR_E_RANGE: a non-finite value, in any chunk of a host-sourced add) leaves the index exactly as it was.
+ * Dynamic range of MDR_STORE_F32X2H: rows are stored times ONE power of two per index, fitted to the first add() and grown (exactly) when a
+ * later add() holds values >= 2^15 times larger; an element keeps fp32 accuracy while it lies within ~2^-14 of the index-wide maximum
+ * |x| (its fp16 hi/lo pair is then normal) and degrades gracefully below that (lo, then hi, go subnormal: relative accuracy 1e-3..1e-4
+ * at 2^-24 of the maximum, zero below ~2^-34). Embedding matrices (unit-scale LayerNorm outputs, the reference's case) sit inside the
+ * accurate range by 10 orders of magnitude; an index mixing rows of wildly different scales is better served by MDR_STORE_BF16 or by
+ * scaling the rows. */
 int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int rows_on_device, void* stream);
 
 int64_t mdr_index_ntotal(const mdr_index* h);

@@ -167,8 +167,9 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
         // Both kernels are bound by the bytes a CU moves over its L2 path, loads AND stores (~20 B/clk/CU measured; skipping
         // the stores made the K = 768 GEMMs 25-30 % faster, deferring them did not): cost = rounds x (tile inputs + outputs).
         // the 256x256 kernels store through a buffer descriptor with 32-bit byte offsets: outputs of 4 GiB and more go to the 256x128 kernel
-        const bool out32 = (unsigned long long)M_cap * (unsigned long long)ldo * (E == EPI_BIAS_F32 ? 4ull : 2ull) < (1ull << 32);
-        const bool a32 = (unsigned long long)M_cap * (unsigned long long)lda * 2ull < (1ull << 32);  // the four-wave kernel also LOADS A through a descriptor
+        // (the offsets of the LAST row tile reach row M + 254: the guard covers M_cap + 255 rows, so that they cannot wrap into valid low rows -- ADVICE r3)
+        const bool out32 = ((unsigned long long)M_cap + 255ull) * (unsigned long long)ldo * (E == EPI_BIAS_F32 ? 4ull : 2ull) < (1ull << 32);
+        const bool a32 = ((unsigned long long)M_cap + 255ull) * (unsigned long long)lda * 2ull < (1ull << 32);  // the four-wave kernel also LOADS A through a descriptor
         if (sel == 7 && out32 && a32 && N % 256 == 0 && K % 128 == 0 && K >= 256) return launch_gemm_quad<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
         if ((sel == 6 || sel == 0) && N % 256 == 0 && out32) {
             const double osz = (E == EPI_BIAS_F32) ? 4.0 : 2.0;

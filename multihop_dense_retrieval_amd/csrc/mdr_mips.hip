@@ -637,12 +637,25 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
     if (rc) return rc;
     int before[16] = {0};  // [0..3] range / query / norm flags, [8..9] the int8 tier's row statistics: all restored when the rows are rejected
     const bool centre_was_set = h->centre_set;
+    const int xexp_was = h->xexp;
+    const bool xexp_was_set = h->xexp_set;
     MDR_HIP_TRY(hipMemcpyAsync(before, h->flags, sizeof(before), hipMemcpyDeviceToHost, st));
     MDR_HIP_TRY(hipStreamSynchronize(st));
+    // ONE rollback for every failure from here on: a rejected add() -- in the first chunk or a later one, by the range check of
+    // fit_exponent or by a conversion kernel's flag -- leaves the index exactly as it was: rows invisible (ntotal unchanged), norm / int8 statistics,
+    // the int8 plane's centre and the exponent as before. (A rescale that an earlier chunk of the same call applied to the stored planes is exact
+    // -- a power of two -- and stays; only the bookkeeping returns, so xexp is restored only when no rescale happened.)
+    auto reject = [&](int code) {
+        (void)hipMemcpyAsync(h->flags, before, sizeof(before), hipMemcpyHostToDevice, st);
+        (void)hipStreamSynchronize(st);
+        h->centre_set = centre_was_set;
+        if (!xexp_was_set) { h->xexp = xexp_was; h->xexp_set = false; }  // the exponent was fitted to rejected rows: forget it
+        return code;
+    };
     const size_t row_src = (size_t)h->d * elem_size(src_dtype);
     if (rows_on_device) {
         rc = add_any(h, rows, src_dtype, n, h->ntotal, st);
-        if (rc) return rc;
+        if (rc) return reject(rc);
     } else {
         // chunked H2D through a device staging buffer (<= 256 MiB), converting straight into the shard
         const long long chunk_rows = (long long)((256ull << 20) / row_src);
@@ -656,22 +669,17 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
         }
         for (long long r0 = 0; r0 < n; r0 += chunk_rows) {
             long long nr = n - r0 < chunk_rows ? n - r0 : chunk_rows;
-            MDR_HIP_TRY(hipMemcpyAsync(h->stage, (const char*)rows + (size_t)r0 * row_src, (size_t)nr * row_src, hipMemcpyHostToDevice, st));
+            if (hipMemcpyAsync(h->stage, (const char*)rows + (size_t)r0 * row_src, (size_t)nr * row_src, hipMemcpyHostToDevice, st) != hipSuccess)
+                return reject(set_error(MDR_E_HIP, "hipMemcpyAsync(host rows) failed"));
             rc = add_any(h, h->stage, src_dtype, nr, h->ntotal + r0, st);
-            if (rc) return rc;
-            MDR_HIP_TRY(hipStreamSynchronize(st));  // staging buffer is reused; host buffer must be consumed before return
+            if (rc) return reject(rc);
+            if (hipStreamSynchronize(st) != hipSuccess) return reject(set_error(MDR_E_HIP, "stream sync failed in add()"));  // staging buffer is reused; host buffer must be consumed before return
         }
     }
     int flag = 0;
     MDR_HIP_TRY(hipMemcpyAsync(&flag, h->flags, sizeof(int), hipMemcpyDeviceToHost, st));
     MDR_HIP_TRY(hipStreamSynchronize(st));
-    if (flag) {
-        // roll back: the rows stay invisible (ntotal unchanged), the norm bound returns to its previous value
-        MDR_HIP_TRY(hipMemcpyAsync(h->flags, before, sizeof(before), hipMemcpyHostToDevice, st));
-        MDR_HIP_TRY(hipStreamSynchronize(st));
-        h->centre_set = centre_was_set;  // a centre taken from rejected rows is forgotten: the next accepted add() defines it
-        return set_error(MDR_E_RANGE, "add(): a value is non-finite; rows were not added");
-    }
+    if (flag) return reject(set_error(MDR_E_RANGE, "add(): a value is non-finite; rows were not added"));
     h->ntotal += n;
     return MDR_OK;
 }

@@ -248,7 +248,8 @@ def _run(args, tokenizer, pool, world, rank):
 
     pipe = TwoHopPipeline(model, index, pool, id2doc, finish_batch, batch_size=args.batch_size, beam=args.beam_size, max_q_len=args.max_q_len,
                           max_q_sp_len=args.max_q_sp_len, roberta=roberta, arena=arena, device=torch.device("cuda", torch.cuda.current_device()),
-                          rank=rank, world=world, depth=args.inflight, fuse=args.pipeline_batches)
+                          rank=rank, world=world, depth=args.inflight, fuse=args.pipeline_batches,
+                          finish_workers=0 if args.num_workers <= 0 else max(1, min(4, args.num_workers // 4)))
 
     def fence():
         if world > 1:
@@ -257,7 +258,10 @@ def _run(args, tokenizer, pool, world, rank):
 
     fence()
     t0 = time.perf_counter()
-    mine = pipe.run(questions, ds_items)
+    try:
+        mine = pipe.run(questions, ds_items)
+    finally:
+        pipe.close()
     fence()
     loop_s = time.perf_counter() - t0
     results = gather_results(mine, world)

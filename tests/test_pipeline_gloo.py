@@ -188,10 +188,12 @@ def test_pipeline_equals_the_sequential_loop(workers, depth, fuse, device_hop2):
     pool = TokenizerPool(tok, workers)
     try:
         pipe = TwoHopPipeline(enc, index, pool, id2doc, finish, batch_size=B, beam=beam, max_q_len=Lq, max_q_sp_len=Lsp, roberta=True,
-                              arena=ToyArena(id2doc, tok) if device_hop2 else None, device="cpu", depth=depth, fuse=fuse)
+                              arena=ToyArena(id2doc, tok) if device_hop2 else None, device="cpu", depth=depth, fuse=fuse,
+                              finish_workers=workers)  # (workers > 0: path ranking / records in forked processes too)
         got = gather_results(pipe.run([mhop.strip_question(it["question"]) for it in items], items), 1)
     finally:
         pool.close()
+        pipe.close()
     same(got, ref)
     assert any(np.isinf(r[1]).any() for r in got)  # the empty passage was retrieved somewhere: the -inf rule is exercised
     assert pipe.stats["batches"] == 5 and pipe.stats["hop1_forwards"] == 5 and pipe.stats["hop2_forwards"] == 5
