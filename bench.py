@@ -519,12 +519,20 @@ def cli_mode(args):
             "--max-q-sp-len", str(args.max_q_sp_len), "--num-workers", str(args.cli_workers)]
     outs = {}
     try:
+        import subprocess
         for name in [x for x in args.cli_legs.split(",") if x]:
             save = os.path.join(out_dir, f"paths_{name}.jsonl")
+            stats = os.path.join(out_dir, f"stats_{name}")
+            # a FRESH process per leg, as a user starts the drop-in script (this process has long touched the device: the CLI's worker processes must
+            # be forked before that); scripts/gpu_cli_multirank.py = eval_mhop_retrieval.main(argv) + its counters (LAST_RUN) left in a file
             t0 = time.perf_counter()
-            metrics, recs = eval_mhop_retrieval.main(base + ["--save-path", save] + legs[name])
+            rcp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_cli_multirank.py"), stats] + base + ["--save-path", save] + legs[name],
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             wall = time.perf_counter() - t0
-            run = dict(eval_mhop_retrieval.LAST_RUN)
+            if rcp.returncode != 0:
+                raise SystemExit(f"CLI leg {name} failed:\n{rcp.stderr[-3000:]}")
+            print(rcp.stderr[-1500:], file=sys.stderr)
+            run = json.load(open(f"{stats}.rank{rank}.json"))
             outs[name] = save
             if rank == 0:
                 done = run["stats"].get("batch_done_t", [])
@@ -533,10 +541,9 @@ def cli_mode(args):
                     steady = round((len(done) - 1 - 8) * B / (done[-1] - done[8]), 2)
                 result[f"cli_{name}"] = {"flags": " ".join(legs[name]) or "(the reference's flags)", "value": round(run["questions"] / run["loop_seconds"], 2),
                                         "unit": "queries/s", "loop_seconds": round(run["loop_seconds"], 4), "ms_per_batch": round(run["loop_seconds"] / max(1, -(-run["questions"] // B)) * 1e3, 4),
-                                        "steady_state_queries_per_s": steady, "whole_main_seconds": round(wall, 2), "records": len(recs), "graph_captures": run["graph_captures"],
+                                        "steady_state_queries_per_s": steady, "whole_process_seconds": round(wall, 2), "records": sum(1 for _ in open(save)), "graph_captures": run["graph_captures"],
                                         "graph_replays": run["graph_replays"], "encoder_forward_calls": run["encoder_forward_calls"],
                                         "stats": {k: v for k, v in run["stats"].items() if k != "batch_done_t"}}
-            torch.cuda.empty_cache()
         if rank == 0 and len(outs) == 2:
             a, b = (open(p).read() for p in outs.values())
             result["legs_jsonl_identical"] = a == b

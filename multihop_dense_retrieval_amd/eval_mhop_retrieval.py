@@ -98,11 +98,16 @@ def load_corpus(corpus_dict, use_store, rank=0, world=1):
         return mhop.load_corpus_dict(corpus_dict)
     from .corpus_store import build_store
     store = corpus_dict + ".store"
-    if rank == 0 and (not os.path.exists(store) or os.path.getmtime(store) < os.path.getmtime(corpus_dict)):
+    def fresh():
+        return os.path.exists(store) and os.path.getmtime(store) >= os.path.getmtime(corpus_dict)
+
+    if rank == 0 and not fresh():
         logger.info("Building the corpus store once...")
-        build_store(corpus_dict, store)
-    if world > 1:
-        torch.distributed.barrier()
+        build_store(corpus_dict, store)  # (written to a temporary name and renamed: a reader never sees a partial file)
+    if world > 1:  # the other ranks wait for the file, not for a collective: this runs before the process touches the device
+        import time
+        while not fresh():
+            time.sleep(0.2)
     return mhop.load_corpus_dict(store)
 
 
@@ -170,11 +175,8 @@ def main(argv=None, tokenizer=None):
 def _run(args, tokenizer, pool, world, rank):
     import time
 
-    from .pipeline import TwoHopPipeline, gather_results
+    from .pipeline import FinishPool, TwoHopPipeline, gather_results
     dist = torch.distributed
-    if world > 1 and not dist.is_initialized():
-        torch.cuda.set_device(0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(args.dist_backend)
 
     logger.info("Loading data...")
     with open(args.raw_data) as f:
@@ -182,20 +184,66 @@ def _run(args, tokenizer, pool, world, rank):
     if args.only_eval_ans:  # eval_mhop_retrieval.py:76-77: yes/no questions cannot be matched against passage text
         ds_items = [it for it in ds_items if it["answer"][0] not in ["yes", "no"]]
 
+    # Start-up order. The reference goes model -> index -> corpus (:80-135). Here everything that lives on the HOST comes first -- checkpoint into
+    # host memory, corpus -- then the worker processes that finish batches are forked (they inherit the corpus and must not inherit a live HIP
+    # runtime: forked after it, every device allocation of the parent -- workspace, hipGraph instantiation -- took ~50x longer, 6.5 s of captures
+    # measured), and only then the process touches the device: process group, weights, index. The log lines are the reference's; "Loading corpus..."
+    # now comes before "Building index...".
     logger.info("Loading trained model...")
     bert_config = _load_config(args.model_name)
     model = RobertaRetriever(bert_config, args)
-    model = load_saved(model, args.model_path, exact=False)
+    model = load_saved(model, args.model_path, exact=False, map_location="cpu")
+
+    logger.info("Loading corpus...")
+    id2doc = load_corpus(args.corpus_dict, args.corpus_store, rank, world)
+    logger.info(f"Corpus size {len(id2doc)}")
+
+    class _Memo(dict):
+        """Per-batch view of id2doc: a passage is looked up (corpus store: decoded from the map) once, however many chains name it."""
+
+        def __missing__(self, key):
+            v = self[key] = corpus[key]
+            return v
+
+    corpus = id2doc
+
+    def finish_batch(batch_ann, D, I, D_, I_):
+        """Path ranking, metrics and output records of one batch (eval_mhop_retrieval.py:181-258); runs in a finishing process (or, with
+        --num-workers 0, on the finisher thread)."""
+        chains = mhop.rank_paths(D, I, D_, I_, args.beam_size, args.topk)
+        ms, recs = [], []
+        id2doc = _Memo()
+        for ann, ch in zip(batch_ann, chains):
+            if args.only_eval_ans:  # answer-string recall over the retrieved chains; nothing is saved (:208-217)
+                ms.append(answer_recall.answer_metrics(ann, ch, id2doc))
+                continue
+            m = mhop.question_metrics(ch, ann["sp"], id2doc)
+            m.update(question=ann["question"], type=ann["type"])
+            ms.append(m)
+            recs.append(mhop.output_record(ann, ch, id2doc))
+        return ms, recs
+
+    finish_pool = FinishPool(finish_batch, 0 if args.num_workers <= 0 else max(1, min(4, args.num_workers // 4)))
+    try:
+        return _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, bert_config, model, id2doc, finish_batch)
+    finally:
+        finish_pool.close()
+
+
+def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, bert_config, model, id2doc, finish_batch):
+    import time
+
+    from .pipeline import TwoHopPipeline, gather_results
+    dist = torch.distributed
+    if world > 1 and not dist.is_initialized():
+        torch.cuda.set_device(0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(args.dist_backend)
     model.to(torch.device("cuda"))
     model.eval()
     model.capture_on_first_use = True  # the loop repeats two shapes (B x max_q_len, B*beam x max_q_sp_len): their hipGraphs are captured at the first batch
 
     logger.info("Building index...")
     index = load_index(args.indexpath, d=bert_config.hidden_size, storage=args.index_storage)
-
-    logger.info("Loading corpus...")
-    id2doc = load_corpus(args.corpus_dict, args.corpus_store, rank, world)
-    logger.info(f"Corpus size {len(id2doc)}")
 
     roberta = "roberta" in args.model_name
     arena = None
@@ -222,34 +270,9 @@ def _run(args, tokenizer, pool, world, rank):
     logger.info("Encoding questions and searching")
     questions = [mhop.strip_question(it["question"]) for it in ds_items]
 
-    class _Memo(dict):
-        """Per-batch view of id2doc: a passage is looked up (corpus store: decoded from the map) once, however many chains name it."""
-
-        def __missing__(self, key):
-            v = self[key] = corpus[key]
-            return v
-
-    corpus = id2doc
-
-    def finish_batch(batch_ann, D, I, D_, I_):
-        """Path ranking, metrics and output records of one batch (eval_mhop_retrieval.py:181-258); runs on the finisher thread."""
-        chains = mhop.rank_paths(D, I, D_, I_, args.beam_size, args.topk)
-        ms, recs = [], []
-        id2doc = _Memo()
-        for ann, ch in zip(batch_ann, chains):
-            if args.only_eval_ans:  # answer-string recall over the retrieved chains; nothing is saved (:208-217)
-                ms.append(answer_recall.answer_metrics(ann, ch, id2doc))
-                continue
-            m = mhop.question_metrics(ch, ann["sp"], id2doc)
-            m.update(question=ann["question"], type=ann["type"])
-            ms.append(m)
-            recs.append(mhop.output_record(ann, ch, id2doc))
-        return ms, recs
-
     pipe = TwoHopPipeline(model, index, pool, id2doc, finish_batch, batch_size=args.batch_size, beam=args.beam_size, max_q_len=args.max_q_len,
                           max_q_sp_len=args.max_q_sp_len, roberta=roberta, arena=arena, device=torch.device("cuda", torch.cuda.current_device()),
-                          rank=rank, world=world, depth=args.inflight, fuse=args.pipeline_batches,
-                          finish_workers=0 if args.num_workers <= 0 else max(1, min(4, args.num_workers // 4)))
+                          rank=rank, world=world, depth=args.inflight, fuse=args.pipeline_batches, finish_pool=finish_pool)
 
     def fence():
         if world > 1:

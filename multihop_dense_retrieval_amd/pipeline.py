@@ -170,9 +170,11 @@ class TwoHopPipeline:
     PAIR_CHUNK = 25  # (question, passage) pairs per tokenizer task
 
     def __init__(self, model, index, pool, id2doc, finish, *, batch_size, beam, max_q_len, max_q_sp_len, roberta=True, arena=None,
-                 device=None, rank=0, world=1, group=None, depth=None, fuse=False, finish_workers=0):
+                 device=None, rank=0, world=1, group=None, depth=None, fuse=False, finish_workers=0, finish_pool=None):
         self.model, self.index, self.pool, self.id2doc, self.finish = model, index, pool, id2doc, finish
-        self.finish_pool = FinishPool(finish, finish_workers)
+        # finish_pool: made by the caller BEFORE it touched the device (the CLI); finish_workers: made here (tests, tools)
+        self._own_finish_pool = finish_pool is None
+        self.finish_pool = finish_pool if finish_pool is not None else FinishPool(finish, finish_workers)
         self.B, self.beam, self.Lq, self.Lsp, self.roberta = int(batch_size), int(beam), int(max_q_len), int(max_q_sp_len), roberta
         self.arena = arena
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -190,7 +192,8 @@ class TwoHopPipeline:
         self._h2d_ring, self._d2h_free, self._d2h_lock = {}, {}, threading.Lock()
 
     def close(self):
-        self.finish_pool.close()
+        if self._own_finish_pool:
+            self.finish_pool.close()
 
     @staticmethod
     def _has_lanes(model):

@@ -314,11 +314,12 @@ class RobertaCtxEncoder(_HipRobertaEncoder):
     __call__ = forward
 
 
-def load_saved(model, path, exact=True):
+def load_saved(model, path, exact=True, map_location=None):
     """utils.py:10-22 -- load a (possibly `module.`-prefixed) state dict; exact=False drops keys the model
-    does not have, then loads strictly (so a MISSING key still raises)."""
+    does not have, then loads strictly (so a MISSING key still raises). map_location (not in the reference): "cpu" keeps a checkpoint that was
+    saved from GPU tensors in host memory (the drop-in CLI loads it before it touches the device; the weights are uploaded by model.to())."""
     try:
-        state_dict = torch.load(path)
+        state_dict = torch.load(path) if map_location is None else torch.load(path, map_location=map_location)
     except Exception:
         state_dict = torch.load(path, map_location=torch.device("cpu"))
 

@@ -10,6 +10,6 @@ r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("device_loop", r.get("device_loop"))
 for k in ("cli_default", "cli_device"):
     if k in r:
-        print(k, {x: r[k][x] for x in ("value", "ms_per_batch", "steady_state_queries_per_s", "whole_main_seconds")}, r[k]["stats"])
+        print(k, {x: r[k][x] for x in ("value", "ms_per_batch", "steady_state_queries_per_s", "whole_process_seconds")}, r[k]["stats"])
 print("ratio", r.get("cli_over_device_loop"), "identical", r.get("legs_jsonl_identical"))
 PY

@@ -62,14 +62,14 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys, tiny_roberta_tokenizer):
     data = tmp_path / "qas.json"
     data.write_text("\n".join(json.dumps(q) for q in qs))
     out = tmp_path / "paths.jsonl"
-    metrics, recs = eval_mhop_retrieval.main([str(data), path, str(save / "id2doc.json"), str(ckpt), "--batch-size", "10", "--beam-size", "3",
+    metrics, recs = eval_mhop_retrieval.main([str(data), path, str(save / "id2doc.json"), str(ckpt), "--num-workers", "2", "--batch-size", "10", "--beam-size", "3",
                                               "--topk", "4", "--model-name", str(cfg_dir), "--gpu", "--save-path", str(out),
                                               "--max-q-len", "12", "--max-q-sp-len", "40"], tokenizer=tok)
     lines = out.read_text().strip().split("\n")
     assert len(lines) == 23 and len(metrics) == 23
     # --hop2-on-device (token arena + mdr_assemble_hop2) must reproduce the host-tokenised run exactly
     out2 = tmp_path / "paths_dev.jsonl"
-    metrics2, recs2 = eval_mhop_retrieval.main([str(data), path, str(save / "id2doc.json"), str(ckpt), "--batch-size", "10", "--beam-size", "3",
+    metrics2, recs2 = eval_mhop_retrieval.main([str(data), path, str(save / "id2doc.json"), str(ckpt), "--num-workers", "0", "--batch-size", "10", "--beam-size", "3",
                                                 "--topk", "4", "--model-name", str(cfg_dir), "--gpu", "--save-path", str(out2),
                                                 "--max-q-len", "12", "--max-q-sp-len", "40", "--hop2-on-device"], tokenizer=tok)
     assert out2.read_text() == out.read_text() and metrics2 == metrics
@@ -77,7 +77,7 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys, tiny_roberta_tokenizer):
     # the host-tokenizer path and on the device-assembly path (23 questions in batches of 10: a ragged last batch)
     for extra in ([], ["--hop2-on-device"]):
         out6 = tmp_path / ("paths_pipe%d.jsonl" % len(extra))
-        metrics6, _ = eval_mhop_retrieval.main([str(data), path, str(save / "id2doc.json"), str(ckpt), "--batch-size", "10", "--beam-size", "3",
+        metrics6, _ = eval_mhop_retrieval.main([str(data), path, str(save / "id2doc.json"), str(ckpt), "--num-workers", "0", "--batch-size", "10", "--beam-size", "3",
                                                 "--topk", "4", "--model-name", str(cfg_dir), "--gpu", "--save-path", str(out6),
                                                 "--max-q-len", "12", "--max-q-sp-len", "40", "--pipeline-batches"] + extra, tokenizer=tok)
         assert out6.read_text() == out.read_text() and metrics6 == metrics
@@ -90,7 +90,7 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys, tiny_roberta_tokenizer):
         assert needle in err, needle
     # bf16 index from the sidecar + memory-mapped corpus store: same chains unless bf16 rounding swaps a near-tie
     out5 = tmp_path / "paths_bf16.jsonl"
-    metrics5, recs5 = eval_mhop_retrieval.main([str(data), path, str(save / "id2doc.json"), str(ckpt), "--batch-size", "10", "--beam-size", "3",
+    metrics5, recs5 = eval_mhop_retrieval.main([str(data), path, str(save / "id2doc.json"), str(ckpt), "--num-workers", "0", "--batch-size", "10", "--beam-size", "3",
                                                 "--topk", "4", "--model-name", str(cfg_dir), "--gpu", "--save-path", str(out5), "--max-q-len", "12",
                                                 "--max-q-sp-len", "40", "--index-storage", "bf16", "--corpus-store"], tokenizer=tok)
     assert (save / "id2doc.json.store").exists() and len(recs5) == 23
@@ -105,7 +105,7 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys, tiny_roberta_tokenizer):
     data_a.write_text("\n".join(json.dumps(q) for q in qa))
     out3 = tmp_path / "paths_ans.jsonl"
     capsys.readouterr()
-    m3, r3 = eval_mhop_retrieval.main([str(data_a), path, str(save / "id2doc.json"), str(ckpt), "--batch-size", "10", "--beam-size", "3",
+    m3, r3 = eval_mhop_retrieval.main([str(data_a), path, str(save / "id2doc.json"), str(ckpt), "--num-workers", "0", "--batch-size", "10", "--beam-size", "3",
                                        "--topk", "4", "--model-name", str(cfg_dir), "--gpu", "--save-path", str(out3), "--max-q-len", "12",
                                        "--max-q-sp-len", "40", "--only-eval-ans"], tokenizer=tok)
     kept = [q for q in qa if q["answer"][0] != "yes"]
