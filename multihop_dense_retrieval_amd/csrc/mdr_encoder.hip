@@ -173,14 +173,25 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
         if (sel == 7 && out32 && a32 && N % 256 == 0 && K % 128 == 0 && K >= 256) return launch_gemm_quad<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
         if ((sel == 6 || sel == 0) && N % 256 == 0 && out32) {
             const double osz = (E == EPI_BIAS_F32) ? 4.0 : 2.0;
-            const double c_big = persistent_rounds(M_est, 256, N, 256, num_cus / 8) * ((256.0 + 256.0) * K * 2 + 256.0 * 256.0 * osz);
+            // the 256x256 kernels walk only the row tiles that fill complete rounds and finish the rest on 128x128 tiles (gemm_head_row_tiles): cost =
+            // complete rounds x big tile + passes x small tile (latency-bound: counted 1.5 x its bytes)
+            const int grid = num_cus / 8 * 8, ntm_all = (M_est + 255) / 256;
+            auto cost256 = [&](int max_rem, int tiles_per_pass, int* rounds_out) {
+                const int head = gemm_head_row_tiles(ntm_all, N / 256, grid, max_rem);
+                const int rounds = persistent_rounds(std::min(M_est, head * 256), 256, N, 256, num_cus / 8);
+                const long long tail_tiles = (long long)((std::max(0, M_est - head * 256) + 127) / 128) * (N / 128);
+                const long long passes = (tail_tiles + (long long)grid * tiles_per_pass - 1) / ((long long)grid * tiles_per_pass);
+                if (rounds_out) *rounds_out = rounds;
+                return rounds * ((256.0 + 256.0) * K * 2 + 256.0 * 256.0 * osz) + passes * 1.5 * ((128.0 + 128.0) * K * 2 + 128.0 * 128.0 * osz);
+            };
+            int rounds_q = 0;
+            const double c_quad = cost256(grid / 4, 1, &rounds_q), c_big = cost256(grid / 2, 2, nullptr);
             const double c_p = persistent_rounds(M_est, 256, N, 128, num_cus / 8) * ((256.0 + 128.0) * K * 2 + 256.0 * 128.0 * osz);
-            if (sel == 6 || c_big < c_p) {
+            if (sel == 6 || std::min(c_big, c_quad) < c_p) {
                 // four waves of 128x128 (gemm_quad_kernel): a faster K-loop (fewer LDS reads, one barrier per K-tile) behind a slower epilogue (one
                 // wave per SIMD has nobody to hide its latencies). Measured at 20.3 k rows: FFN2 77 vs 83-86 us, out-projection 30-33 vs 31-37,
                 // but QKV 84-89 vs 70-72 and FFN1 113-123 vs 106-117 (three / four tiles per workgroup, K = 768): taken where the K-loop dominates.
-                const int rounds = persistent_rounds(M_est, 256, N, 256, num_cus / 8);
-                if (sel == 0 && a32 && K % 128 == 0 && K >= 256 && (rounds == 1 || K >= 2048))
+                if (sel == 0 && a32 && K % 128 == 0 && K >= 256 && (rounds_q == 1 || K >= 2048) && c_quad <= 1.15 * c_big)
                     return launch_gemm_quad<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
                 return launch_gemm_big<E>(A, lda, W, bias, M_cap, M_dev, N, K, out, ldo, M_est, num_cus, st);
             }

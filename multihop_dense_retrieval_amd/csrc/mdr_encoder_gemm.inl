@@ -190,6 +190,122 @@ gemm_f16_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
     }
 }
 
+// ---- tail of the persistent 256x256 kernels: the last, partial round on 128x128 tiles ------------------------------------------
+// T = ntm x ntn tiles of 256x256 over G persistent workgroups take ceil(T / G) rounds; when T is a little over a multiple of G the last round
+// keeps a few workgroups busy for a whole tile time while the rest of the chip idles (86 row tiles of 256 x N = 768: 258 tiles = TWO rounds on 256
+// CUs for one round of work -- the +37 % step at 21.8 k tokens of DESIGN.md section 4). gemm_head_row_tiles() gives the 256x256 walk only the row
+// tiles that fill COMPLETE rounds; the remaining rows (fewer than max_rem + ntn tiles' worth) are computed by the same workgroups afterwards on
+// 128x128 tiles (gemm_tail_tile: the one-tile-per-block kernel's K-loop on a 2-slot ring, one tile per group of four waves), which spreads them
+// over 4x as many units. Same K order and MFMA per output element as every other flavour: bit-identical results.
+__host__ __device__ inline int gemm_head_row_tiles(int ntm, int ntn, int G, int max_rem) {
+    const long long T = (long long)ntm * ntn;
+    const long long full = T / G, rem = T % G;
+    if (full < 1 || rem == 0 || rem > max_rem) return ntm;
+    return (int)(full * G / ntn);
+}
+
+// The tail's MFMAs are spelled as asm with VGPR accumulators: gemm_quad_kernel keeps a[0:255] live ACROSS its asm statements, so the compiler must not
+// be given a reason to touch an AGPR anywhere in that kernel (its own MFMA form put these 64 accumulators there: scripts/check_quad_agprs.py). Hazards
+// the compiler would otherwise cover: the accumulate chain has SrcC == vDst of the same opcode (no wait states needed); the first read of an accumulator
+// by the VALU comes behind gemm_tail_settle() (32 wait states > the 8 passes of the last MFMA); operands come from LDS (the compiler waits on lgkmcnt
+// for asm inputs as for any other use).
+__device__ __forceinline__ void mfma16_vgpr(f32x4& acc, half8 a, half8 b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void gemm_tail_settle(f32x4 (&acc)[4][4]) {
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]),
+                   "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
+}
+
+// One 128x128 tile by a GROUP of four waves (tg = thread in the group 0..255, wg = wave in the group 0..3) on a 64 KiB ring at `ring`. Contains
+// workgroup barriers: every wave of the workgroup must call it the same number of times with the same K. valid = false (a group without a tile in the
+// last pass): m0 >= M, i.e. loads on the clamped last row, no stores.
+template <int EPI>
+__device__ __forceinline__ void gemm_tail_tile(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M,
+                                               int K, void* __restrict__ out, int ldo, int m0, int n0, char* ring, int tg, int wg, int lane) {
+    constexpr int BM = 128, BN = 128, THREADS = 256, MT = 4, NT = 4, A_CHUNKS = 4, W_CHUNKS = 4;
+    constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2;
+    const int wm = wg >> 1, wn = wg & 1;
+    const int g = lane >> 4, lr = lane & 15;
+    const _Float16* a_src[A_CHUNKS];
+    const _Float16* w_src[W_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) {
+        const int p = i * THREADS + tg;
+        const int row = p >> 3, s = (p & 7) ^ (row & 7);
+        int ar = m0 + row;
+        ar = ar < M ? ar : M - 1;
+        a_src[i] = A + (size_t)ar * lda + s * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < W_CHUNKS; ++i) {
+        const int p = i * THREADS + tg;
+        const int row = p >> 3, s = (p & 7) ^ (row & 7);
+        w_src[i] = W + (size_t)(n0 + row) * K + s * 8;
+    }
+    auto issue = [&](int stage, int k0) __attribute__((always_inline)) {
+        char* base = ring + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i)
+            __builtin_amdgcn_global_load_lds(MDR_GPTR(a_src[i] + k0), MDR_LPTR(base + (i * THREADS + wg * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < W_CHUNKS; ++i)
+            __builtin_amdgcn_global_load_lds(MDR_GPTR(w_src[i] + k0), MDR_LPTR(base + A_BYTES + (i * THREADS + wg * 64) * 16), 16, 0, 0);
+    };
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gemm_tail_settle(acc);  // (the zeros are VALU writes: keep them well ahead of the first asm MFMA that reads them as SrcC)
+    const int sw0 = ((0 * 4 + g) ^ (lane & 7)) << 4, sw1 = ((1 * 4 + g) ^ (lane & 7)) << 4;
+    const int a_off = (wm * MT * 16 + lr) * 128, w_off = A_BYTES + (wn * NT * 16 + lr) * 128;
+    const int KT = K / BK;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everybody is done with the ring (the previous tile's last K-step, or the 256x256 walk)
+    asm volatile("" ::: "memory");
+    issue(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < KT) issue((kt + 1) & 1, (kt + 1) * BK);
+        const char* base = ring + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int sw = s ? sw1 : sw0;
+            half8 af[MT], wf[NT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[t] = *(const half8*)(base + a_off + t * 16 * 128 + sw);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[t] = *(const half8*)(base + w_off + t * 16 * 128 + sw);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mfma16_vgpr(acc[mt][nt], wf[nt], af[mt]);
+        }
+    }
+    gemm_tail_settle(acc);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + (wm * MT + mt) * 16 + lr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + (wn * NT + nt) * 16 + 4 * g;
+            const f32x4 b4 = *(const f32x4*)(bias + n);
+            f32x4 v = acc[mt][nt] + b4;
+            if (EPI == EPI_BIAS_GELU_F16) v = gelu_erf4(v);
+            if (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
+                *(scr_u32x2*)((_Float16*)out + (size_t)m * ldo + n) = cvt_pk_half4(v);
+            } else {
+                *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
+            }
+        }
+    }
+}
+
 // ---- persistent GEMM for large M ------------------------------------------------------------------------
 // K is short here (768 or 3072): a one-tile-per-block kernel spends as long filling and draining its LDS ring
 // as computing. This kernel keeps ONE 512-thread block per CU alive and walks (tile, k-step) as one flat stream:
@@ -459,13 +575,15 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
     const int M = M_dev ? min(*M_dev, M_cap) : M_cap;
     // output descriptor: raw buffer over rows [0, M) -- stores to rows past M (the last, partial row tile) are dropped by its bounds check
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(((unsigned)(M - 1) * (unsigned)ldo + (unsigned)N) * ((EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) ? 2u : 4u)), 0x00020000);
-    const int ntn = N / 256, ntm = (M + 255) / 256;
+    const int ntn = N / 256;
+    const int ntm = gemm_head_row_tiles((M + 255) / 256, ntn, gridDim.x, gridDim.x / 2);  // row tiles of the 256x256 walk; the rows behind them: gemm_tail_tile, below
     const long long T_all = (long long)ntm * ntn;  // tile order and XCD ownership: see gemm_persist_kernel
     const int xcd = blockIdx.x & 7;
     const int t_base = (int)(T_all * xcd / 8), local_tiles = (int)(T_all * (xcd + 1) / 8) - t_base;
     const int lb = blockIdx.x >> 3, G = gridDim.x >> 3;
-    if (lb >= local_tiles) return;
-    const int n_my = (local_tiles - lb + G - 1) / G;
+    const int tail_m0 = ntm * 256;
+    if (lb >= local_tiles && tail_m0 >= M) return;
+    const int n_my = lb < local_tiles ? (local_tiles - lb + G - 1) / G : 0;
     auto tile_origin = [&](int j, int& m0, int& n0) __attribute__((always_inline)) {
         const int t = t_base + lb + j * G;
         m0 = (t / ntn) * 256;
@@ -518,6 +636,7 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
     const int sw0 = ((0 * 4 + g) ^ (lane & 7)) << 4, sw1 = ((1 * 4 + g) ^ (lane & 7)) << 4;
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bias loads, before any DMA is in flight
+    if (n_my > 0) {
     set_load_tile(0);
     // prologue: K-tile 0 completely, then the first 6 pieces of K-tile 1 (what sub-phases 1-3 of a step -1 would have issued)
 #pragma unroll
@@ -525,6 +644,7 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
     next_ktile();
 #pragma unroll
     for (int c = 0; c < 2; ++c) issue_piece(c);  // "sub-phase 4 of step -1"
+    }
     dma_on = false;
 
     f32x4 acc[8][4];
@@ -667,6 +787,16 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus pieces must have landed before the LDS is released
+    if (tail_m0 < M) {  // (uniform over the grid) the partial last round, on 128x128 tiles: two per pass, one per group of four waves
+        const int ttn = N / 128, Tt = ((M - tail_m0 + 127) / 128) * ttn;
+        const int grp = wave >> 2;
+        for (int p = (int)blockIdx.x * 2; p < Tt; p += (int)gridDim.x * 2) {
+            const int t = p + grp;
+            const bool valid = t < Tt;
+            gemm_tail_tile<EPI>(A, lda, W, bias, M, K, out, ldo, valid ? tail_m0 + (t / ttn) * 128 : M, valid ? (t % ttn) * 128 : 0, lds + grp * 65536, tid & 255,
+                                wave & 3, lane);
+        }
+    }
 #if MDR_GEMM_ABL == 5
     stamp(6);
     if (tid == 0) {

@@ -81,13 +81,15 @@ gemm_quad_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __rest
     float* lds_bias = (float*)(lds + C::LDS_BYTES);
     if ((unsigned)(size_t)lds != 0u) __builtin_trap();  // the generated K-loop XORs slot addresses: the ring has to start at LDS address 0
     const int M = M_dev ? min(*M_dev, M_cap) : M_cap;
-    const int ntn = N / 256, ntm = (M + 255) / 256;
+    const int ntn = N / 256;
+    const int ntm = gemm_head_row_tiles((M + 255) / 256, ntn, gridDim.x, gridDim.x / 4);  // row tiles of the 256x256 walk; the rows behind them: gemm_tail_tile, below
     const long long T_all = (long long)ntm * ntn;  // tile order and XCD ownership: see gemm_persist_kernel
     const int xcd = blockIdx.x & 7;
     const int t_base = (int)(T_all * xcd / 8), local_tiles = (int)(T_all * (xcd + 1) / 8) - t_base;
     const int lb = blockIdx.x >> 3, G = gridDim.x >> 3;
-    if (lb >= local_tiles) return;
-    const int n_my = (local_tiles - lb + G - 1) / G;
+    const int tail_m0 = ntm * 256;
+    if (lb >= local_tiles && tail_m0 >= M) return;
+    const int n_my = lb < local_tiles ? (local_tiles - lb + G - 1) / G : 0;
     auto tile_origin = [&](int j, int& m0, int& n0) __attribute__((always_inline)) {
         const int t = t_base + lb + j * G;
         m0 = (t / ntn) * 256;
@@ -168,4 +170,9 @@ gemm_quad_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __rest
         quad_epilogue_rows<EPI, 7>(scr, b8, out_rsrc, o_col, o_lane, ldo_b, g, lr);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus pieces must have landed before the LDS is released
+    if (tail_m0 < M) {  // (uniform over the grid) the partial last round, on 128x128 tiles (mdr_encoder_gemm.inl: gemm_tail_tile); plain compiled code, behind every K-loop statement
+        const int ttn = N / 128, Tt = ((M - tail_m0 + 127) / 128) * ttn;
+        for (int t = (int)blockIdx.x; t < Tt; t += (int)gridDim.x)
+            gemm_tail_tile<EPI>(A, lda, W, bias, M, K, out, ldo, tail_m0 + (t / ttn) * 128, (t % ttn) * 128, lds, tid, wave, lane);
+    }
 }

@@ -81,3 +81,43 @@ def test_gemm_device_side_row_count(kernel):
     ref = _reference(A, W, bias, 3)
     assert (out[:valid].double() - ref[:valid]).abs().max().item() <= 2e-3
     assert bool(torch.isnan(out[valid:]).all())
+
+
+# (M, N, K) a little over a whole number of rounds of 256x256 tiles on 256 workgroups: the last, partial round runs on 128x128 tiles inside the same
+# persistent kernel (gemm_head_row_tiles / gemm_tail_tile). 86 row tiles: 258 / 774 / 1032 tiles for N = 768 / 2304 / 3072 (remainders 2 / 6 / 8);
+# 171 x 3 = 513 (two complete rounds + 1); 43 x 12 = 516 (remainder 4, rows not a multiple of 128); a tail of several row tiles (N = 768: 90 x 3 = 270).
+TAIL_SHAPES = [(22013, 768, 768), (22013, 2304, 768), (22013, 3072, 768), (22013, 768, 3072), (43700, 768, 768), (10900, 3072, 768), (22990, 768, 768)]
+
+
+@pytest.mark.parametrize("kernel", [6, 7])
+@pytest.mark.parametrize("epilogue", [0, 1, 3])
+@pytest.mark.parametrize("shape", TAIL_SHAPES)
+def test_partial_last_round_on_small_tiles_is_bit_identical(shape, epilogue, kernel):
+    """Every flavour accumulates K in the same order with the same MFMA: the 256x256 kernels with their 128x128 tail must return the bits of the
+    one-tile-per-block 128x128 kernel (2), whose results the fp64 test above pins, for every row -- head tiles, tail tiles and the ragged last rows."""
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 1)
+    A = torch.randn((M, K), generator=g, device="cuda").half()
+    W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).half()
+    bias = torch.randn((N,), generator=g, device="cuda")
+    out = _gemm(A, W, bias, epilogue, kernel)
+    ref = _gemm(A, W, bias, epilogue, 2)
+    assert bool(torch.isfinite(out.float()).all())
+    assert torch.equal(out, ref), f"{shape} epilogue {epilogue} kernel {kernel}: {int((out != ref).sum())} elements differ, first rows {torch.nonzero((out != ref).any(1))[:5].flatten().tolist()}"
+    err = (out.double() - _reference(A, W, bias, epilogue)).abs()
+    assert err.max().item() <= (2e-3 if epilogue == 3 else 2e-2)
+
+
+@pytest.mark.parametrize("kernel", [6, 7])
+def test_tail_respects_the_device_side_row_count(kernel):
+    """The split point is computed on the device from *m_dev: rows past it stay untouched whether they fall in the 256x256 walk or in the tail."""
+    M, N, K = 23000, 768, 768
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A = torch.randn((M, K), generator=g, device="cuda").half()
+    W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).half()
+    bias = torch.zeros((N,), device="cuda")
+    ref = _reference(A, W, bias, 3)
+    for valid in (21761, 21900, 22016, 22017, 22700):  # 86 row tiles (tail of one) ... 89 (tail of four)
+        out = _gemm(A, W, bias, 3, kernel, m_valid=valid)
+        assert (out[:valid].double() - ref[:valid]).abs().max().item() <= 2e-3, valid
+        assert bool(torch.isnan(out[valid:]).all()), valid
