@@ -35,6 +35,9 @@ TOL = {"tiny": (6e-3, 1.2e-3), "base": (1.2e-2, 2e-3)}
 #   (b) HIP-o1ops / e_regime  tiny 0.64-0.68 / 0.82-0.86   wide2 0.67-0.71 / 0.75   base 0.76-0.78 / 0.77-0.82
 # i.e. the HIP encoder sits where a second correct O1 implementation sits (the CPU restatement vs the hooked reference: 0.28-0.80).
 O1_BARS = {"tiny": (1.15, 0.80), "wide2": (1.10, 0.80), "base": (1.08, 0.88)}
+# residual_fp32 = 2 against the literal-apex-O1 fixture (e_lit = mean |o1lit - fp32| ~ 1.3 x e_regime): (HIP-fp32, HIP-o1lit) as multiples of e_lit.
+# Measured (round 4, MI355X, profiles/r04_encoder_o1_distances.txt): see DESIGN.md section 4; the bars leave ~10 % over the largest measured ratio.
+O1_LIT_BARS = {"tiny": (1.05, 0.95), "wide2": (1.05, 0.95), "base": (1.05, 0.95)}
 
 
 def build(geom, seed, cls=None, residual_fp32=None):
@@ -65,20 +68,26 @@ def test_encode_q_matches_reference(models, golden, tag, name):
     assert err.max() <= TOL[tag][0] and err.mean() <= TOL[tag][1]
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("tag,name", [("tiny", "qsp"), ("base", "q"), ("base", "qsp")])
-def test_fp32_residual_stream_mode_matches_reference(golden, tag, name):
-    """mdr_encoder_config.residual_fp32 = 1: LayerNorm outputs stay fp32 for the residual adds (the reference's apex-O1 regime)."""
+def test_other_residual_stream_modes_match_reference(golden, tag, name, mode):
+    """mdr_encoder_config.residual_fp32 = 1 (fp32 residual stream + fp32 Linear sums) and 0 (fp16 residual copy); the default, 2, is what
+    test_encode_q_matches_reference runs."""
     g = golden(f"encoder_{tag}.npz")
-    m, _ = build(seeded.TINY if tag == "tiny" else seeded.ROBERTA_BASE, 11 if tag == "tiny" else 7, residual_fp32=True)
+    m, _ = build(seeded.TINY if tag == "tiny" else seeded.ROBERTA_BASE, 11 if tag == "tiny" else 7, residual_fp32=mode)
     out = m.encode_q(torch.from_numpy(g[f"{name}.ids"]).cuda(), torch.from_numpy(g[f"{name}.mask"]).cuda(), None)
     err = np.abs(out.cpu().numpy() - g[f"{name}.embed"])
-    print(f"encoder {tag}.{name} (fp32 residual): max abs err {err.max():.3e} mean {err.mean():.3e}")
+    print(f"encoder {tag}.{name} (residual_fp32={mode}): max abs err {err.max():.3e} mean {err.mean():.3e}")
     assert err.max() <= TOL[tag][0] and err.mean() <= TOL[tag][1]
 
 
-@pytest.mark.parametrize("residual_fp32", [True, False])
+@pytest.mark.parametrize("residual_fp32", [2, 1, 0])
 @pytest.mark.parametrize("tag,name", [("tiny", "q"), ("tiny", "qsp"), ("wide2", "q"), ("wide2", "qsp"), ("base", "q"), ("base", "qsp")])
 def test_distance_to_the_operand_rounded_reference(golden, tag, name, residual_fp32):
+    """residual_fp32 = 1: the `o1ops` dataflow (fp32 residual stream, fp32 Linear sums); 0: one more fp16 rounding per LayerNorm (not O1-faithful);
+    2 (the default since round 4): fp32 residual stream with the out-projection / FFN2 outputs rounded to fp16 before the residual add -- what LITERAL
+    apex O1 computes around the LayerNorms (`embed_o1lit` also rounds the scores, the probabilities and the pre-GELU sums, which this build keeps in
+    fp32): its bar is against the literal-O1 fixture, relative to THAT regime's own error e_lit = mean |o1lit - fp32|."""
     g = golden(f"encoder_{tag}.npz")
     geom = {"tiny": seeded.TINY, "wide2": seeded.WIDE2, "base": seeded.ROBERTA_BASE}[tag]
     m, _ = build(geom, int(g["seed"]), residual_fp32=residual_fp32)
@@ -90,8 +99,15 @@ def test_distance_to_the_operand_rounded_reference(golden, tag, name, residual_f
           f"({d32.mean() / e_regime:.2f} x) | HIP-o1ops mean {dops.mean():.3e} max {dops.max():.3e} ({dops.mean() / e_regime:.2f} x) | "
           f"HIP-o1lit mean {dlit.mean():.3e} max {dlit.max():.3e}")
     A, B = O1_BARS[tag]
-    if not residual_fp32:  # one more fp16 rounding per LayerNorm than apex O1 performs (the default, faster mode): reported, looser
+    if residual_fp32 == 0:  # one more fp16 rounding per LayerNorm than apex O1 performs (the fastest mode): reported, looser
         A, B = A + 0.10, B + 0.10
+    if residual_fp32 == 2:
+        e_lit = np.abs(lit - f32).mean()
+        print(f"   literal-O1 regime error e_lit {e_lit:.3e}: HIP-o1lit / e_lit {dlit.mean() / e_lit:.2f}, HIP-fp32 / e_lit {d32.mean() / e_lit:.2f}")
+        assert d32.mean() <= O1_LIT_BARS[tag][0] * e_lit, (d32.mean(), e_lit)     # no further from fp32 than literal apex O1 itself is
+        assert dlit.mean() <= O1_LIT_BARS[tag][1] * e_lit, (dlit.mean(), e_lit)   # and inside the regime's own noise of the literal-O1 outputs
+        assert dlit.max() <= 4.0 * np.abs(lit - f32).max()
+        return
     assert d32.mean() <= A * e_regime, (d32.mean(), e_regime)
     assert dops.mean() <= B * e_regime, (dops.mean(), e_regime)
     assert dops.max() <= 4.0 * np.abs(ops - f32).max()
