@@ -237,7 +237,9 @@ bool wide_pass(int nq) {
     return !off && nq > kStreamQ;
 }
 bool stream_kernel_supports(const mdr_index* h, int k) { return !is_bf16(h) && h->d == 768 && k <= 128; }
-bool screen_kernel_supports(const mdr_index* h, int k) { return h->d == 768 && k <= 128; }
+bool screen_kernel_supports(const mdr_index* h, int k) { return h->d == 768 && k <= 256; }
+// sample stages per workgroup of the k > 1 screen (mips_screen_kernel MODE 2): one published maximum per stage
+int sample_stages_for(int k) { return k > 128 ? 2 * kSampleStagesK : kSampleStagesK; }
 
 enum Path { PATH_GENERIC = 1, PATH_STREAM = 2, PATH_SCREEN = 3 };
 
@@ -279,13 +281,14 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     const long long n_rb = (h->ntotal + 15) / 16;
     const long long units = p.path == PATH_SCREEN ? (h->ntotal + 31) / 32 : n_rb;
     p.G = (int)(units < h->num_cus ? (units > 0 ? units : 1) : h->num_cus);
-    if (p.G > 1024) p.G = 1024;  // kth_of_maxima_kernel holds one value per workgroup in LDS
+    if (p.G > 1024) p.G = 1024;
     p.Gx = (int)(n_rb < h->num_cus ? (n_rb > 0 ? n_rb : 1) : h->num_cus);
     const long long gg = (long long)h->num_cus * 2;
     p.Gg = (int)(n_rb < gg ? (n_rb > 0 ? n_rb : 1) : gg);
     // which candidate-list workspaces this call can touch (incl. the conditional exact pass behind the screen kernel)
-    p.lists_stream = (p.path == PATH_STREAM || (p.path == PATH_SCREEN && !is_bf16(h))) && k > 1;
-    p.lists_generic = p.path == PATH_GENERIC || (p.path == PATH_SCREEN && is_bf16(h));
+    // (the exact pass behind the screen-k kernels: the MFMA stream kernel up to its k = 128, the generic kernel for bf16 rows and for 128 < k <= 256)
+    p.lists_stream = (p.path == PATH_STREAM || (p.path == PATH_SCREEN && !is_bf16(h) && stream_kernel_supports(h, k))) && k > 1;
+    p.lists_generic = p.path == PATH_GENERIC || (p.path == PATH_SCREEN && (is_bf16(h) || !stream_kernel_supports(h, k)));
     const bool screenk = p.path == PATH_SCREEN && k > 1;
     const bool frag = p.path != PATH_GENERIC;
     const size_t nq_pad = (size_t)((nq + kWideQ - 1) / kWideQ) * kWideQ;  // covers both group sizes (128 and 256 queries per pass)
@@ -305,7 +308,7 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
         p.G8w = (int)((units + 1) / 2 < h->num_cus ? ((units + 1) / 2 > 0 ? (units + 1) / 2 : 1) : h->num_cus);  // the 32-queries-per-wave kernel: one per CU, stages of two super-blocks
     }
     const size_t gl = p.i8 && p.G8 > p.G ? (size_t)p.G8 : (size_t)p.G;  // workgroups that own candidate lists
-    p.off_scand = take(p.path != PATH_SCREEN ? 0 : (k == 1 ? gl * 8 * kWaveCandCap * 8 : (size_t)p.G * kWideQ * 4));
+    p.off_scand = take(p.path != PATH_SCREEN ? 0 : (k == 1 ? gl * 8 * kWaveCandCap * 8 : (size_t)p.G * sample_stages_for(k) * kWideQ * 4));
     p.off_sctl = take(p.path == PATH_SCREEN ? 256 + gl * 8 * 4 : 0);            // [0] overflow flag, [64..] per-wave counts
     // the screen-k lists and the lists of its conditional exact pass (which runs after them in stream order) share one region
     size_t lists = p.lists_stream ? (size_t)p.Gx * kStreamQ * kStreamCap : (p.lists_generic ? (size_t)p.Gg * kGenericQ * kGenericCap : 0);
@@ -513,6 +516,7 @@ int run_screenk(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
     const int ngroups = (nq + kStreamQ - 1) / kStreamQ;
     const int nq_pad = ngroups * kStreamQ;
     const int n_sb = (int)((h->ntotal + 31) / 32);
+    const int stages = sample_stages_for(k);
     const size_t qgroup_bytes = (size_t)kStreamQ * h->d * 2;
     MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
     for (int gi = 0; gi < ngroups; ++gi) {
@@ -521,9 +525,10 @@ int run_screenk(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
         const float* bg = bound + (size_t)gi * kStreamQ;
         float* tg = tau0 + (size_t)gi * kStreamQ;
         MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * kStreamQ * 4, st));
+        MDR_HIP_TRY(hipMemsetAsync(wgmax, 0, (size_t)p.G * stages * kStreamQ * 4, st));
         hipLaunchKernelGGL((mips_screen_kernel<NKB, 2, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg, nqg,
-                           gi * kStreamQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr);
-        hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G, k, tg, kStreamQ);
+                           gi * kStreamQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, stages);
+        hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G * stages, k, tg, kStreamQ);
         hipLaunchKernelGGL((mips_screenk_kernel<NKB, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg,
                            (const float*)tg, nqg, cand, cnt, k, sctl);
         hipLaunchKernelGGL((merge_screenk_kernel<BF>), dim3(nqg), dim3(256), merge_lds, st, (const u64*)cand, (const int*)cnt, p.G, k, bg, (const char*)h->hi,
@@ -553,6 +558,7 @@ int run_screenk32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_de
     int* cnt = (int*)(ws + p.off_cnt);
     const int ngroups = (nq + kWideQ - 1) / kWideQ;
     const int n_sb = (int)((h->ntotal + 31) / 32);
+    const int stages = sample_stages_for(k);
     const size_t qgroup_bytes = (size_t)kWideQ * h->d * 2;
     MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
     for (int gi = 0; gi < ngroups; ++gi) {
@@ -561,9 +567,10 @@ int run_screenk32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_de
         const float* bg = bound + (size_t)gi * kWideQ;
         float* tg = tau0 + (size_t)gi * kWideQ;
         MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * kWideQ * 4, st));
+        MDR_HIP_TRY(hipMemsetAsync(wgmax, 0, (size_t)p.G * stages * kWideQ * 4, st));
         hipLaunchKernelGGL((mips_screen32_kernel<NKB, 2, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg, nqg,
-                           gi * kWideQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr);
-        hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G, k, tg, kWideQ);
+                           gi * kWideQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, stages);
+        hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G * stages, k, tg, kWideQ);
         hipLaunchKernelGGL((mips_screenk32_kernel<NKB, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg,
                            (const float*)tg, nqg, cand, cnt, k, sctl);
         hipLaunchKernelGGL((merge_screenk_kernel<BF>), dim3(nqg), dim3(256), merge_lds, st, (const u64*)cand, (const int*)cnt, p.G, k, bg, (const char*)h->hi,
@@ -811,7 +818,7 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
         return MDR_OK;
     }
 
-    // 2 <= k <= 128
+    // 2 <= k <= 256 (screen path; the exact stream kernel behind / instead of it serves k <= 128)
     const int* run_if = nullptr;
     if (p.path == PATH_SCREEN) {
         if (wide_pass(nq)) {
@@ -826,6 +833,7 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
         if (rc) return rc;
         run_if = (const int*)(ws + p.off_sctl);  // exact pass below: only if a list or the band overflowed
         if (bf) return run_generic<true>(h, p, ws, q_dev, nq, k, D_dev, I_ll, id_offset, run_if, st);
+        if (!stream_kernel_supports(h, k)) return run_generic<false>(h, p, ws, q_dev, nq, k, D_dev, I_ll, id_offset, run_if, st);
     } else {
         h->last_kernel = "mips_stream_kernel<24,1>";
     }

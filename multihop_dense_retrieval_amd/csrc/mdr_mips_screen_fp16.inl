@@ -34,7 +34,8 @@ template <int NKB, int MODE, bool BF>
 __global__ void __launch_bounds__(512, 2)
 mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, const char* __restrict__ Qhi, const float* __restrict__ qbound, int nq,
                    int q_base, unsigned* __restrict__ gmax /* [nq] ordered(max s_hi) */, u64* __restrict__ cand /* [waves][kWaveCandCap] */,
-                   int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow, const int* __restrict__ run_if = nullptr) {
+                   int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow, const int* __restrict__ run_if = nullptr,
+                   int sample_stages = kSampleStagesK /* MODE 2: stages per workgroup; gmax is [G * sample_stages][kStreamQ], one maximum per stage */) {
     if (run_if && *run_if == 0) return;  // behind the int8 tier: only when one of its lists overflowed
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SB_BYTES = 2 * NKB * kFragBytes;
@@ -46,7 +47,7 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
     int n_it = (n_sb - b + G - 1) / G;  // >= 1 (grid <= n_sb)
     if (MODE == 0 && n_it > kSampleStages) n_it = kSampleStages;
     int step_ = 1;  // MODE 2 spreads its sample stages over the workgroup's whole row range
-    if (MODE == 2 && n_it > kSampleStagesK) { step_ = n_it / kSampleStagesK; n_it = kSampleStagesK; }
+    if (MODE == 2 && n_it > sample_stages) { step_ = n_it / sample_stages; n_it = sample_stages; }
     const int sG = (MODE == 2 ? step_ : 1) * G;  // super-block stride between consecutive stages
 
     issue_super_block<NKB>(Xhi, b, lds, wave, lane);
@@ -170,15 +171,18 @@ mips_screen_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, con
             hm = fmaxf(hm, __shfl_xor(hm, 32));
             known = fmaxf(known, hm);
         }
+        if (MODE == 2) {  // one maximum per (workgroup, stage, query): 32 disjoint rows each, so the k-th largest of them is a bound on the k-th best row
+            float hm = fmaxf(hmax, __shfl_xor(hmax, 16));
+            hm = fmaxf(hm, __shfl_xor(hm, 32));
+            if (lane < 16 && q_valid) gmax[((size_t)b * sample_stages + it) * kStreamQ + qlocal] = hm > -FLT_MAX ? ord32(hm) : 0u;
+            hmax = -FLT_MAX;
+        }
     }
     if (MODE == 0) {
         float hm = fmaxf(hmax, __shfl_xor(hmax, 16));
         hm = fmaxf(hm, __shfl_xor(hm, 32));
         if (lane < 16 && q_valid && hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
-    } else if (MODE == 2) {  // per-workgroup maxima (no atomics): gmax is [G][kStreamQ] here
-        float hm = fmaxf(hmax, __shfl_xor(hmax, 16));
-        hm = fmaxf(hm, __shfl_xor(hm, 32));
-        if (lane < 16 && q_valid) gmax[(size_t)b * kStreamQ + qlocal] = hm > -FLT_MAX ? ord32(hm) : 0u;
+    } else if (MODE == 2) {  // (published per stage, above; the host zeroes the table first: a workgroup with fewer stages leaves zeros = "no row")
     } else if (lane == 0) {
         cand_cnt[b * 8 + wave] = my_cnt < kWaveCandCap ? my_cnt : kWaveCandCap;
         if (my_cnt > kWaveCandCap) *overflow = 1;
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(512, 2)
 mips_screen32_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, const char* __restrict__ Qhi, const float* __restrict__ qbound, int nq,
                      int q_base, unsigned* __restrict__ gmax /* [nq] ordered(max s_hi); MODE 2: [G][kWideQ] */,
                      u64* __restrict__ cand /* [waves][kWaveCandCap] */, int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow,
-                     const int* __restrict__ run_if = nullptr) {
+                     const int* __restrict__ run_if = nullptr, int sample_stages = kSampleStagesK /* MODE 2: gmax is [G * sample_stages][kWideQ] */) {
     if (run_if && *run_if == 0) return;  // behind the int8 tier: only when one of its lists overflowed
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SB_BYTES = 2 * NKB * kFragBytes;
@@ -259,7 +263,7 @@ mips_screen32_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, c
     int n_it = (n_sb - b + G - 1) / G;  // >= 1 (grid <= n_sb)
     if (MODE == 0 && n_it > kSampleStages) n_it = kSampleStages;
     int step_ = 1;
-    if (MODE == 2 && n_it > kSampleStagesK) { step_ = n_it / kSampleStagesK; n_it = kSampleStagesK; }
+    if (MODE == 2 && n_it > sample_stages) { step_ = n_it / sample_stages; n_it = sample_stages; }
     const int sG = (MODE == 2 ? step_ : 1) * G;
 
     issue_super_block<NKB>(Xhi, b, lds, wave, lane);
@@ -345,13 +349,16 @@ mips_screen32_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, c
             }
         }
         if (MODE == 1) known = fmaxf(known, fmaxf(hmax, __shfl_xor(hmax, 32)));  // the two lanes of a query share their maxima
+        if (MODE == 2) {  // one maximum per (workgroup, stage, query), see mips_screen_kernel
+            const float hm = fmaxf(hmax, __shfl_xor(hmax, 32));
+            if (lane < 32 && q_valid) gmax[((size_t)b * sample_stages + it) * kWideQ + qlocal] = hm > -FLT_MAX ? ord32(hm) : 0u;
+            hmax = -FLT_MAX;
+        }
     }
     if (MODE == 0) {
         const float hm = fmaxf(hmax, __shfl_xor(hmax, 32));
         if (lane < 32 && q_valid && hm > -FLT_MAX) atomicMax(gmax + qlocal, ord32(hm));
-    } else if (MODE == 2) {
-        const float hm = fmaxf(hmax, __shfl_xor(hmax, 32));
-        if (lane < 32 && q_valid) gmax[(size_t)b * kWideQ + qlocal] = hm > -FLT_MAX ? ord32(hm) : 0u;
+    } else if (MODE == 2) {  // (published per stage, above)
     } else if (lane == 0) {
         cand_cnt[b * 8 + wave] = my_cnt < kWaveCandCap ? my_cnt : kWaveCandCap;
         if (my_cnt > kWaveCandCap) *overflow = 1;
@@ -405,11 +412,13 @@ mips_refine_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, i
     }
 }
 
-// ---- the screen kernel for 2 <= k <= 128: hi plane only, per-(workgroup, query) lists keyed by s_hi ---------
+// ---- the screen kernel for 2 <= k <= 256: hi plane only, per-(workgroup, query) lists keyed by s_hi ---------
 // A row can be among the k best exact scores only if s_hi >= h_k - 2B, h_k = k-th largest s_hi over ALL rows
 // (k rows have exact >= h_k - B, and s_hi < h_k - 2B means exact < h_k - B). Any lower bound on h_k will do:
-//   1. sample pass (mips_screen_kernel MODE 2): every workgroup scores kSampleStagesK super-blocks and publishes its
-//      largest s_hi per query; the k-th largest of those G maxima (k distinct rows!) is the first bound (tau0).
+//   1. sample pass (mips_screen_kernel MODE 2): every workgroup scores kSampleStagesK (k > 128: twice as many) super-blocks and publishes the
+//      largest s_hi of EACH per query; the k-th largest of those G x stages maxima (k distinct rows!) is the first bound (tau0). (Rounds 1-3 kept one
+//      maximum per workgroup: at k = 250 the 250th of 256 maxima is a bound ~36 k rows deep per query at 5 M rows; per-stage maxima of a 262 k-row
+//      sample put it ~5 k deep, inside what the merge kernel holds, which is what lets the screen path take k up to 256.)
 //   2. main pass: rows with s_hi >= bound - 2B are appended to the (workgroup, query) list; should a list run full it
 //      is pruned to (its own k-th largest) - 2B, which becomes that list's bound. Bounds only rise and never exceed
 //      h_k, so the union of the lists holds every possible winner.
@@ -461,24 +470,21 @@ __device__ inline u64 wave_select_band(u64* list, int c, int k, float band2, int
     return t;
 }
 
-// k-th largest of the G per-workgroup sample maxima of each query -> tau0 (-inf when fewer than k workgroups saw a row)
-__global__ void __launch_bounds__(256) kth_of_maxima_kernel(const unsigned* __restrict__ wgmax /* [G][qcap] ordered, 0 = none */, int G, int k,
+// k-th largest of the V = G x stages sample maxima of each query (one per workgroup and sample stage: disjoint 32-row blocks, i.e. distinct rows) -> tau0
+// (-inf when fewer than k blocks saw a row). Bisection on the ordered 32-bit key: V is 4 k - 32 k values, read from L2 each step.
+__global__ void __launch_bounds__(256) kth_of_maxima_kernel(const unsigned* __restrict__ wgmax /* [V][qcap] ordered, 0 = none */, int V, int k,
                                                             float* __restrict__ tau0 /* [qcap] */, int qcap) {
     const int ql = blockIdx.x;
-    __shared__ unsigned v[1024];
-    __shared__ int found;
-    if (threadIdx.x == 0) found = 0;
-    for (int i = threadIdx.x; i < G; i += 256) v[i] = wgmax[(size_t)i * qcap + ql];
-    __syncthreads();
-    for (int i = threadIdx.x; i < G; i += 256) {
-        const unsigned me = v[i];
-        if (me == 0u) continue;
-        int rank = 0;
-        for (int j = 0; j < G; ++j) rank += (v[j] > me) || (v[j] == me && j < i);
-        if (rank == k - 1) { tau0[ql] = unord32(me); found = 1; }
+    __shared__ int red[4];
+    unsigned t = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned c = t | (1u << bit);
+        int n = 0;
+        for (int i = threadIdx.x; i < V; i += 256) n += wgmax[(size_t)i * qcap + ql] >= c;
+        n = block_sum_256(n, red);
+        if (n >= k) t = c;
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && !found) tau0[ql] = -INFINITY;
+    if (threadIdx.x == 0) tau0[ql] = t ? unord32(t) : -INFINITY;  // t == 0: fewer than k non-empty blocks
 }
 
 template <int NKB, bool BF>
