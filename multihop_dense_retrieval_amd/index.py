@@ -263,6 +263,10 @@ class ShardedIndexFlatIP:
             D, I = self.local.search(q, k)
             return self.search_gathered(D, I, force=force)
         block, _, _ = self.local.search_device_packed(q, k)
+        return self.exchange_packed(block, nq, k)
+
+    def exchange_packed(self, block, nq, k):
+        """The exchange step alone: this rank's packed (D, I) block (IndexFlatIP.search_device_packed) -> merged lists, identical on all ranks."""
         gathered = all_gather_dim0(block, self.world, self.group)
         return topk_merge_packed(gathered, self.world, nq, k)
 

@@ -244,12 +244,14 @@ class SyntheticTwoHop:
 
     def _search(self, q, k):
         e0 = self._mark()
-        D, I = self.local.search_device(q, k)
-        e1 = self._mark()
-        self._search_ev.append((e0, e1, int(q.shape[0])))  # the local MIPS launch only (roofline), not the exchange
         if self.world == 1:
+            D, I = self.local.search_device(q, k)
+            self._search_ev.append((e0, self._mark(), int(q.shape[0])))
             return D, I
-        return self.index.search_gathered(D, I)
+        # N > 1: the shard's lists land in the packed exchange block, ONE all-gather moves every rank's block, ONE kernel merges them
+        block, _, _ = self.local.search_device_packed(q, k)
+        self._search_ev.append((e0, self._mark(), int(q.shape[0])))  # the local MIPS launch only (roofline), not the exchange
+        return self.index.exchange_packed(block, int(q.shape[0]), k)
 
     # -- software-pipelined step ------------------------------------------------------------------------------
     def _hop1_only(self):

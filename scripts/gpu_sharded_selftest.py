@@ -44,6 +44,8 @@ def main():
             Dl, Il = sh.local.search_device(q, beam)
             kern = sh.local.last_kernel()
             D, I = sh.search_gathered(Dl, Il)
+            Dp, Ip = sh.search_device(q, beam)  # the packed exchange (search -> block, one all-gather, mdr_topk_merge_packed): the same lists, bit for bit
+            ok &= bool(torch.equal(Ip, I) and torch.equal(Dp, D))
             # identical on every rank: compare a checksum through the group
             sig = torch.stack([I.sum().double(), (I * torch.arange(1, I.numel() + 1, device=dev).view_as(I)).sum().double(), D.double().sum()]).cpu()
             sigs = [torch.zeros_like(sig) for _ in range(world)]
