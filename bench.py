@@ -13,7 +13,7 @@ N > 1   : launched by torch.distributed.run, one rank per GPU. The 5M-row corpus
           its shard, ONE all_gather per hop exchanges the per-shard top-k lists, every rank merges and continues with its
           own questions. Per-GPU work is then constant in N (100 sequences through the encoder; rows/N x queries*N
           through the MIPS). --scaling strong keeps ONE 100-question batch and splits the encoder slices instead; a
-          10 ms step of 2 x 12 dependent transformer layers is latency-bound there.
+          10 ms step of 2 x 12 dependent transformer layers is latency-bound there (NEGATIVE_RESULTS.md §3.6).
 Prints ONE JSON line on rank 0 with
   roofline          the MIPS kernel (HBM-bound): PHYSICAL HBM bytes per search call / HIP-event time of the call on the launch
                     stream / 8 TB/s. The screen kernels stream only the int8 screening plane (beam = 1: 776 B per row) or the

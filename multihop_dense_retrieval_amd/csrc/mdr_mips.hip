@@ -1,7 +1,7 @@
 // csrc/mdr_mips.hip -- brute-force maximum-inner-product search for gfx950 (MI355X).
 //
 // Replaces faiss.IndexFlatIP.{add,search} as the reference uses them
-// (/root/reference/scripts/eval/eval_mhop_retrieval.py:121-122,155,179). See DESIGN.md §3.
+// (/root/reference/scripts/eval/eval_mhop_retrieval.py:121-122,155,179). See DESIGN.md §3-4 (layout, kernels) and NEGATIVE_RESULTS.md §3 (how they got there).
 //
 // Storage (MDR_STORE_F32X2H). Every fp32 element x is kept as an fp16 pair
 //     hi = fp16(x)            lo = fp16((x - hi) * 2^11)          x ~= hi + lo * 2^-11   (22-bit mantissa)

@@ -271,7 +271,7 @@ class SyntheticTwoHop:
     def _step_pipelined(self):
         """Batches are independent, so hop 2 of batch i and hop 1 of batch i+1 run as TWO CONCURRENT encoder forwards (two lanes
         = two workspaces and graph caches on two streams, the same weights; one merged 22.6 k-token forward measured slower,
-        DESIGN.md §6) and share ONE fused corpus pass (B*beam + B queries; more than 128 queries go 256 per pass). Every
+        NEGATIVE_RESULTS.md §6) and share ONE fused corpus pass (B*beam + B queries; more than 128 queries go 256 per pass). Every
         question still walks hop-1 encode -> search -> hop-2 assembly -> hop-2 encode -> search -> path ranking with the same
         arithmetic; what changes is that the small, latency-bound hop-1 forward runs beside the previous batch's large hop-2
         forward and that its queries ride in that batch's corpus pass. In the steady state one call finishes one batch and
