@@ -103,6 +103,8 @@ def parse():
                     help="pipelined (default): hop 2 of batch i beside hop 1 of batch i+1, then their ONE corpus pass; deep: two batches in flight -- the corpus pass "
                          "of step i (hop 2 of batch i + hop 1 of batch i+2) on its own stream beside the encoder forwards of step i+1. Measured round 4: 14.91 k vs "
                          "14.87 k queries/s -- both kernels fill every CU, the pass takes 1.55 instead of 1.12 ms and the encoder stage 6.58 instead of 5.54 (DESIGN.md)")
+    ap.add_argument("--hop1-group", type=int, default=1,
+                    help="pipelined loop: the side-stream hop-1 forward encodes the questions of this many future batches at once, every that-many-th step")
     ap.add_argument("--no-sequential", action="store_true", help="pipelined run: do not append the sequential sub-result")
     ap.add_argument("--no-anisotropic", action="store_true", help="do not append the anisotropic-corpus MIPS sub-result (N = 1, beam 1)")
     ap.add_argument("--aniso-m", type=float, nargs="*", default=[20.0, 200.0], help="norms m of the common component of the anisotropic sub-result")
@@ -602,7 +604,9 @@ def main():
     pipe = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device,
                                 max_q_len=args.max_q_len, max_q_sp_len=args.max_q_sp_len,
                                 use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank, world=world, weak=weak,
-                                pipelined=False if args.sequential else (2 if args.loop == "deep" else True), pool=args.pool)
+                                pipelined=False if args.sequential else (2 if args.loop == "deep" else True), pool=args.pool, hop1_group=args.hop1_group)
+    if pipe.encoder is not None and args.hop1_group > 1:
+        pipe.encoder.capture_on_first_use = True  # a grouped hop-1 shape recurs only every G-th step: capture it at its first sighting (in the warm-up)
     out, elapsed = timed_steps(pipe, args, world, device, dist)
 
     # self-checks, outside the timed region: structural properties + exactness against a brute-force pass over ALL rows

@@ -132,7 +132,7 @@ class SyntheticTwoHop:
     VOCAB = 50265
 
     def __init__(self, index, batch, beam, topk, dim, device, max_q_len=70, max_q_sp_len=350, use_encoder=True,
-                 planted_rows=None, rank=0, world=1, weak=False, pipelined=False, pool=1):
+                 planted_rows=None, rank=0, world=1, weak=False, pipelined=False, pool=1, hop1_group=1):
         """`weak=False`: ONE batch of `batch` questions shared by all ranks (strong scaling: the encoder work is split).
         `weak=True`: every rank owns its own batch of `batch` questions (global batch = batch * world): it encodes them,
         the embeddings of all ranks are all-gathered, every rank searches ALL of them in its row shard, the per-shard
@@ -142,7 +142,8 @@ class SyntheticTwoHop:
         self.use_encoder = use_encoder
         self.pipelined = bool(pipelined)
         self.deep = pipelined == 2 or pipelined == "deep"  # two batches deep: the corpus pass on its own stream beside the next step's encoders
-        self._carry = None  # pipelined mode: (q, D, I) of the batch whose hop 1 is already done
+        self._ready = collections.deque()  # pipelined mode: (q, D, I) of the upcoming batches whose hop 1 is already done, in order
+        self.hop1_group = max(1, int(hop1_group))  # pipelined mode: the hop-1 forward encodes the questions of this many future batches at once
         self._deep = collections.deque()  # deep mode: (q, D, I, event) of the two batches whose hop 1 is done or in flight
         self._side = None   # side stream of the pipelined loop
         self._search_stream = None
@@ -277,38 +278,51 @@ class SyntheticTwoHop:
         forward and that its queries ride in that batch's corpus pass. In the steady state one call finishes one batch and
         starts the next, i.e. per step exactly one hop-1 and one hop-2 of every kind of work, as in the sequential step.
         `stage_ms()["hop2_encode"]` of this loop is the wall time of BOTH forwards (main stream, waits for the side stream)."""
-        if self._carry is None:
-            self._carry = self._hop1_only()
+        G = self.hop1_group
+        if not self._ready:
+            self._ready.append(self._hop1_only())
             self._search_ev = self._search_ev[:-1] if self._search_ev else self._search_ev  # the prologue is not a timed call
-        q, D, I = self._carry
+        q, D, I = self._ready.popleft()
+        refill = not self._ready  # the next batch's hop 1 is not done yet: this step carries the hop 1 of the next G batches
         B, bm = self.B, self.beam
+        nxt = [self.batches[(self._cur + 1 + j) % self.pool] for j in range(G)] if refill else []
         ev = [self._mark()]
         ev.append(ev[0])  # (no separate hop-1 stages)
         ev.append(ev[0])
+        q_next = None
         if self.use_encoder:
-            # the next batch's questions on a side stream / second encoder lane, beside this batch's hop-2 forward: ~140 short,
-            # latency-bound launches that fill the gaps of the large forward instead of running alone
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)  # (a high-priority side stream measured the same: 7.21 vs 7.26 ms)
-            start = torch.cuda.Event()
-            start.record()
-            self._side.wait_event(start)
-            nb = self._nxt()
-            with torch.cuda.stream(self._side):
-                q_next = self._encode(nb["q_ids"], nb["q_mask"], lane=1)
-                done = torch.cuda.Event()
-                done.record()
+            done = None
+            if refill:
+                # the next batches' questions on a side stream / second encoder lane, beside this batch's hop-2 forward: short, latency-bound
+                # launches that fill the gaps of the large forward instead of running alone. hop1_group = G > 1 (round 4): the questions of the next
+                # G batches as ONE forward every G-th step -- G x the tokens per launch instead of G x the launches
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)  # (a high-priority side stream measured the same: 7.21 vs 7.26 ms)
+                start = torch.cuda.Event()
+                start.record()
+                self._side.wait_event(start)
+                n_ids = nxt[0]["q_ids"] if G == 1 else torch.cat([b_["q_ids"] for b_ in nxt], 0)
+                n_mask = nxt[0]["q_mask"] if G == 1 else torch.cat([b_["q_mask"] for b_ in nxt], 0)
+                with torch.cuda.stream(self._side):
+                    q_next = self._encode(n_ids, n_mask, lane=1)
+                    done = torch.cuda.Event()
+                    done.record()
+                n_ids.record_stream(self._side)
+                n_mask.record_stream(self._side)
             ids, mask = self._hop2_inputs(I, D)  # hop-2 inputs of batch i
             ev.append(self._mark())
             q2 = self._encode(ids, mask)
-            torch.cuda.current_stream().wait_event(done)
-            q_next.record_stream(torch.cuda.current_stream())
-            e = torch.cat([q2, q_next], 0) if not self.weak else self._interleave(q2, q_next)
+            if refill:
+                torch.cuda.current_stream().wait_event(done)
+                q_next.record_stream(torch.cuda.current_stream())
+                e = torch.cat([q2, q_next], 0) if not self.weak else self._interleave(q2, q_next)
+            else:
+                e = q2
         else:
             ids = mask = None
             ev.append(self._mark())
             q2 = (0.5 * q).repeat_interleave(bm, 0) + self.table[(I.reshape(-1) % 1024)]
-            e = torch.cat([q2, self.planted_rows + self._nxt()["noise"]], 0).contiguous()
+            e = torch.cat([q2] + [self.planted_rows + b_["noise"] for b_ in nxt], 0).contiguous()
             if self.weak:
                 from .index import all_gather_dim0
                 e = all_gather_dim0(e, self.world)
@@ -316,9 +330,11 @@ class SyntheticTwoHop:
         Dc, Ic = self._search(e.contiguous(), bm)
         if self.weak:
             e, Dc, Ic = self._own(e), self._own(Dc), self._own(Ic)
-        q2, q_next = e[:B * bm], e[B * bm:]
+        q2 = e[:B * bm]
         D2, I2 = Dc[:B * bm].contiguous(), Ic[:B * bm].contiguous()
-        self._carry = (q_next, Dc[B * bm:].contiguous(), Ic[B * bm:].contiguous())
+        for j in range(len(nxt)):
+            lo, hi = B * bm + j * B, B * bm + (j + 1) * B
+            self._ready.append((e[lo:hi], Dc[lo:hi].contiguous(), Ic[lo:hi].contiguous()))
         ev.append(self._mark())
         h1, h2, sc = rank_paths_device(D, I, D2, I2, bm, self.topk)
         ev.append(self._mark())
