@@ -182,10 +182,10 @@ int launch_gemm(const _Float16* A, int lda, const _Float16* W, const float* bias
                 const long long tail_tiles = (long long)((std::max(0, M_est - head * 256) + 127) / 128) * (N / 128);
                 const long long passes = (tail_tiles + (long long)grid * tiles_per_pass - 1) / ((long long)grid * tiles_per_pass);
                 if (rounds_out) *rounds_out = rounds;
-                return rounds * ((256.0 + 256.0) * K * 2 + 256.0 * 256.0 * osz) + passes * 1.5 * ((128.0 + 128.0) * K * 2 + 128.0 * 128.0 * osz);
+                return rounds * ((256.0 + 256.0) * K * 2 + 256.0 * 256.0 * osz) + passes * 1.2 * ((128.0 + 128.0) * K * 2 + 128.0 * 128.0 * osz);
             };
             int rounds_q = 0;
-            const double c_quad = cost256(grid / 4, 1, &rounds_q), c_big = cost256(grid / 2, 2, nullptr);
+            const double c_quad = cost256(grid / 4, 1, &rounds_q), c_big = cost256(grid / 2, 1, nullptr);
             const double c_p = persistent_rounds(M_est, 256, N, 128, num_cus / 8) * ((256.0 + 128.0) * K * 2 + 256.0 * 128.0 * osz);
             if (sel == 6 || std::min(c_big, c_quad) < c_p) {
                 // four waves of 128x128 (gemm_quad_kernel): a faster K-loop (fewer LDS reads, one barrier per K-tile) behind a slower epilogue (one

@@ -195,8 +195,7 @@ gemm_f16_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
 // keeps a few workgroups busy for a whole tile time while the rest of the chip idles (86 row tiles of 256 x N = 768: 258 tiles = TWO rounds on 256
 // CUs for one round of work -- the +37 % step at 21.8 k tokens of DESIGN.md section 4). gemm_head_row_tiles() gives the 256x256 walk only the row
 // tiles that fill COMPLETE rounds; the remaining rows (fewer than max_rem + ntn tiles' worth) are computed by the same workgroups afterwards on
-// 128x128 tiles (gemm_tail_tile: the one-tile-per-block kernel's K-loop on a 2-slot ring, one tile per group of four waves), which spreads them
-// over 4x as many units. Same K order and MFMA per output element as every other flavour: bit-identical results.
+// 128x128 tiles (gemm_tail_tile: the one-tile-per-block kernel's K-loop on a four-slot ring over the whole 128 KiB), which spreads them over 4x as many units. Same K order and MFMA per output element as every other flavour: bit-identical results.
 __host__ __device__ inline int gemm_head_row_tiles(int ntm, int ntn, int G, int max_rem) {
     const long long T = (long long)ntm * ntn;
     const long long full = T / G, rem = T % G;
@@ -218,15 +217,16 @@ __device__ __forceinline__ void gemm_tail_settle(f32x4 (&acc)[4][4]) {
                    "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
 }
 
-// One 128x128 tile by a GROUP of four waves (tg = thread in the group 0..255, wg = wave in the group 0..3) on a 64 KiB ring at `ring`. Contains
-// workgroup barriers: every wave of the workgroup must call it the same number of times with the same K. valid = false (a group without a tile in the
-// last pass): m0 >= M, i.e. loads on the clamped last row, no stores.
-template <int EPI>
+// One 128x128 tile by WGM x WGN waves (tg = thread 0..64 WGM WGN - 1, wg = wave index) on a ring of SLOTS 32 KiB stages at `ring` (SLOTS - 1 DMA batches in
+// flight: with two slots a K-step is one L2 round trip, 1.3 us measured; four bring it to the LDS / MFMA time). Contains workgroup barriers: every wave of the
+// WORKGROUP must call it the same number of times with the same K. A call without a tile (m0 >= M): loads on the clamped last row, no stores.
+template <int EPI, int WGM, int WGN, int SLOTS>
 __device__ __forceinline__ void gemm_tail_tile(const _Float16* __restrict__ A, int lda, const _Float16* __restrict__ W, const float* __restrict__ bias, int M,
                                                int K, void* __restrict__ out, int ldo, int m0, int n0, char* ring, int tg, int wg, int lane) {
-    constexpr int BM = 128, BN = 128, THREADS = 256, MT = 4, NT = 4, A_CHUNKS = 4, W_CHUNKS = 4;
-    constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2;
-    const int wm = wg >> 1, wn = wg & 1;
+    constexpr int BM = 128, BN = 128, THREADS = 64 * WGM * WGN, MT = BM / WGM / 16, NT = BN / WGN / 16, A_CHUNKS = BM * 8 / THREADS, W_CHUNKS = BN * 8 / THREADS;
+    constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2, PER_STAGE = A_CHUNKS + W_CHUNKS;
+    static_assert(MT * NT <= 16 && SLOTS >= 2 && SLOTS <= 4, "accumulators are settled sixteen at a time; the counted waits are written for 2-4 slots");
+    const int wm = wg / WGN, wn = wg % WGN;
     const int g = lane >> 4, lr = lane & 15;
     const _Float16* a_src[A_CHUNKS];
     const _Float16* w_src[W_CHUNKS];
@@ -253,11 +253,11 @@ __device__ __forceinline__ void gemm_tail_tile(const _Float16* __restrict__ A, i
         for (int i = 0; i < W_CHUNKS; ++i)
             __builtin_amdgcn_global_load_lds(MDR_GPTR(w_src[i] + k0), MDR_LPTR(base + A_BYTES + (i * THREADS + wg * 64) * 16), 16, 0, 0);
     };
-    f32x4 acc[MT][NT];
+    f32x4 acc[4][4];  // [MT][NT] used; the settle helper takes all sixteen
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     gemm_tail_settle(acc);  // (the zeros are VALU writes: keep them well ahead of the first asm MFMA that reads them as SrcC)
     const int sw0 = ((0 * 4 + g) ^ (lane & 7)) << 4, sw1 = ((1 * 4 + g) ^ (lane & 7)) << 4;
     const int a_off = (wm * MT * 16 + lr) * 128, w_off = A_BYTES + (wn * NT * 16 + lr) * 128;
@@ -265,13 +265,22 @@ __device__ __forceinline__ void gemm_tail_tile(const _Float16* __restrict__ A, i
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everybody is done with the ring (the previous tile's last K-step, or the 256x256 walk)
     asm volatile("" ::: "memory");
-    issue(0, 0);
+#pragma unroll
+    for (int s_ = 0; s_ < SLOTS - 1; ++s_)
+        if (s_ < KT) issue(s_, s_ * BK);
     for (int kt = 0; kt < KT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // stage kt has landed; at most SLOTS - 2 younger stages stay in flight across the barrier
+        const int younger = min(SLOTS - 2, KT - 1 - kt);
+        if (SLOTS >= 4 && younger >= 2)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_STAGE * 2) : "memory");
+        else if (SLOTS >= 3 && younger >= 1)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_STAGE) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 1 < KT) issue((kt + 1) & 1, (kt + 1) * BK);
-        const char* base = ring + (kt & 1) * STAGE_BYTES;
+        if (kt + SLOTS - 1 < KT) issue((kt + SLOTS - 1) % SLOTS, (kt + SLOTS - 1) * BK);
+        const char* base = ring + (kt % SLOTS) * STAGE_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int sw = s ? sw1 : sw0;
@@ -787,15 +796,10 @@ gemm_big_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __restr
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus pieces must have landed before the LDS is released
-    if (tail_m0 < M) {  // (uniform over the grid) the partial last round, on 128x128 tiles: two per pass, one per group of four waves
+    if (tail_m0 < M) {  // (uniform over the grid) the partial last round, on 128x128 tiles: all eight waves (4 x 2) on one tile, four 32 KiB slots
         const int ttn = N / 128, Tt = ((M - tail_m0 + 127) / 128) * ttn;
-        const int grp = wave >> 2;
-        for (int p = (int)blockIdx.x * 2; p < Tt; p += (int)gridDim.x * 2) {
-            const int t = p + grp;
-            const bool valid = t < Tt;
-            gemm_tail_tile<EPI>(A, lda, W, bias, M, K, out, ldo, valid ? tail_m0 + (t / ttn) * 128 : M, valid ? (t % ttn) * 128 : 0, lds + grp * 65536, tid & 255,
-                                wave & 3, lane);
-        }
+        for (int t = (int)blockIdx.x; t < Tt; t += (int)gridDim.x)
+            gemm_tail_tile<EPI, 4, 2, 4>(A, lda, W, bias, M, K, out, ldo, tail_m0 + (t / ttn) * 128, (t % ttn) * 128, lds, tid, wave, lane);
     }
 #if MDR_GEMM_ABL == 5
     stamp(6);

@@ -173,6 +173,6 @@ gemm_quad_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __rest
     if (tail_m0 < M) {  // (uniform over the grid) the partial last round, on 128x128 tiles (mdr_encoder_gemm.inl: gemm_tail_tile); plain compiled code, behind every K-loop statement
         const int ttn = N / 128, Tt = ((M - tail_m0 + 127) / 128) * ttn;
         for (int t = (int)blockIdx.x; t < Tt; t += (int)gridDim.x)
-            gemm_tail_tile<EPI>(A, lda, W, bias, M, K, out, ldo, tail_m0 + (t / ttn) * 128, (t % ttn) * 128, lds, tid, wave, lane);
+            gemm_tail_tile<EPI, 2, 2, 4>(A, lda, W, bias, M, K, out, ldo, tail_m0 + (t / ttn) * 128, (t % ttn) * 128, lds, tid, wave, lane);
     }
 }

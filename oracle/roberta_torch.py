@@ -11,6 +11,9 @@ the numpy restatement in turn by the reference's own outputs (tests/golden/encod
 that oracle/gen_golden.py produces from the IMPORTED reference model under a torch-function mode):
     "operands"  Linear / matmul inputs and weights rounded to fp16, products and sums in `dtype`, outputs not rounded
     "literal"   additionally the outputs of Linear (matmul result, then the bias add) and of the attention matmuls rounded to fp16
+    "sums16"    "operands" + the outputs of the two Linears in front of the LayerNorms (attention.output.dense, output.dense) rounded to fp16 once,
+                after the bias add, BEFORE the residual add -- the dataflow of mdr_encoder_config.residual_fp32 = 2 (fp32 residual stream; apex O1's
+                F.linear returns fp16 there). Restated, not produced by the imported model: between the two fixture regimes by construction.
 
 Only tests/ (and oracle/gen_golden.py) may import this module.
 """
@@ -27,7 +30,7 @@ def layer_norm(x, g, b, eps):
 
 def encode(sd, geom, input_ids, attention_mask, dtype=torch.float64, device="cpu", chunk=64, o1=None):
     """sd: name -> numpy / torch tensors (fp32 checkpoint values). -> [B, hidden] tensor of `dtype` on `device`."""
-    assert o1 in (None, "operands", "literal")
+    assert o1 in (None, "operands", "literal", "sums16")
     W = {k: torch.as_tensor(v).to(device=device, dtype=dtype) for k, v in sd.items() if "pooler" not in k}
 
     def r(t):  # fp16 rounding of a GEMM operand (or, literal mode, of a GEMM output)
@@ -64,11 +67,13 @@ def encode(sd, geom, input_ids, attention_mask, dtype=torch.float64, device="cpu
             s = ro(r(q) @ r(k).transpose(-1, -2)) / math.sqrt(hd) + add_mask
             pr = torch.softmax(s, -1)
             ctx = ro(r(pr) @ r(v)).permute(0, 2, 1, 3).reshape(B, L, H)
-            x = layer_norm(lin(ctx, "attention.output.dense") + x, W[p + "attention.output.LayerNorm.weight"],
+            def pre_ln(t):  # the Linear output that meets the fp32 residual
+                return t.to(torch.float16).to(dtype) if o1 == "sums16" else t
+            x = layer_norm(pre_ln(lin(ctx, "attention.output.dense")) + x, W[p + "attention.output.LayerNorm.weight"],
                            W[p + "attention.output.LayerNorm.bias"], eps)
             h = lin(x, "intermediate.dense")
             h = 0.5 * h * (1.0 + torch.erf(h / math.sqrt(2.0)))
-            x = layer_norm(lin(h, "output.dense") + x, W[p + "output.LayerNorm.weight"], W[p + "output.LayerNorm.bias"], eps)
+            x = layer_norm(pre_ln(lin(h, "output.dense")) + x, W[p + "output.LayerNorm.weight"], W[p + "output.LayerNorm.bias"], eps)
         y = linear(x[:, 0, :], W["project.0.weight"], W["project.0.bias"])
         outs.append(layer_norm(y, W["project.1.weight"], W["project.1.bias"], eps))
     return torch.cat(outs)

@@ -37,7 +37,8 @@ TOL = {"tiny": (6e-3, 1.2e-3), "base": (1.2e-2, 2e-3)}
 O1_BARS = {"tiny": (1.15, 0.80), "wide2": (1.10, 0.80), "base": (1.08, 0.88)}
 # residual_fp32 = 2 against the literal-apex-O1 fixture (e_lit = mean |o1lit - fp32| ~ 1.3 x e_regime): (HIP-fp32, HIP-o1lit) as multiples of e_lit.
 # Measured (round 4, MI355X, profiles/r04_encoder_o1_distances.txt): see DESIGN.md section 4; the bars leave ~10 % over the largest measured ratio.
-O1_LIT_BARS = {"tiny": (1.05, 0.95), "wide2": (1.05, 0.95), "base": (1.05, 0.95)}
+# measured: HIP-fp32 / e_lit 0.80-0.87, HIP-o1lit / e_lit 0.86-1.05 (the mode rounds two Linear outputs per layer, literal O1 every matmul: independent errors of similar size)
+O1_LIT_BARS = {"tiny": (0.95, 1.15), "wide2": (0.95, 1.15), "base": (0.95, 1.15)}
 
 
 def build(geom, seed, cls=None, residual_fp32=None):
@@ -102,10 +103,17 @@ def test_distance_to_the_operand_rounded_reference(golden, tag, name, residual_f
     if residual_fp32 == 0:  # one more fp16 rounding per LayerNorm than apex O1 performs (the fastest mode): reported, looser
         A, B = A + 0.10, B + 0.10
     if residual_fp32 == 2:
-        e_lit = np.abs(lit - f32).mean()
-        print(f"   literal-O1 regime error e_lit {e_lit:.3e}: HIP-o1lit / e_lit {dlit.mean() / e_lit:.2f}, HIP-fp32 / e_lit {d32.mean() / e_lit:.2f}")
-        assert d32.mean() <= O1_LIT_BARS[tag][0] * e_lit, (d32.mean(), e_lit)     # no further from fp32 than literal apex O1 itself is
-        assert dlit.mean() <= O1_LIT_BARS[tag][1] * e_lit, (dlit.mean(), e_lit)   # and inside the regime's own noise of the literal-O1 outputs
+        # this mode's OWN regime restated (oracle/roberta_torch.py o1="sums16": operand rounding + the two pre-LayerNorm Linear outputs rounded to fp16),
+        # evaluated in fp64 on the device: the sharp bar, like (b) for mode 1. Against the fixtures it sits between the two regimes they hold.
+        from oracle import roberta_torch
+        sd = seeded.make_state_dict(int(g["seed"]), geom)
+        own = roberta_torch.encode(sd, geom, g[f"{name}.ids"], g[f"{name}.mask"], torch.float64, "cuda", chunk=8, o1="sums16").cpu().numpy()
+        e_lit, down = np.abs(lit - f32).mean(), np.abs(out - own)
+        print(f"   mode 2: HIP-own-regime mean {down.mean():.3e} ({down.mean() / e_regime:.2f} x e_regime) | e_lit {e_lit:.3e}: HIP-fp32 / e_lit {d32.mean() / e_lit:.2f}, "
+              f"HIP-o1lit / e_lit {dlit.mean() / e_lit:.2f} | own-regime vs fp32 {np.abs(own - f32).mean() / e_regime:.2f} x e_regime")
+        assert down.mean() <= (B + 0.07) * e_regime, (down.mean(), e_regime)        # as close to its own regime as a second correct implementation is
+        assert d32.mean() <= O1_LIT_BARS[tag][0] * e_lit, (d32.mean(), e_lit)       # closer to fp32 than literal apex O1 itself is
+        assert dlit.mean() <= O1_LIT_BARS[tag][1] * e_lit, (dlit.mean(), e_lit)     # and no further from the literal-O1 outputs than those are from fp32
         assert dlit.max() <= 4.0 * np.abs(lit - f32).max()
         return
     assert d32.mean() <= A * e_regime, (d32.mean(), e_regime)
