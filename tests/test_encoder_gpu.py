@@ -38,6 +38,9 @@ O1_BARS = {"tiny": (1.15, 0.80), "wide2": (1.10, 0.80), "base": (1.08, 0.88)}
 # residual_fp32 = 2 against the literal-apex-O1 fixture (e_lit = mean |o1lit - fp32| ~ 1.3 x e_regime): (HIP-fp32, HIP-o1lit) as multiples of e_lit.
 # Measured (round 4, MI355X, profiles/r04_encoder_o1_distances.txt): see DESIGN.md section 4; the bars leave ~10 % over the largest measured ratio.
 # measured: HIP-fp32 / e_lit 0.80-0.87, HIP-o1lit / e_lit 0.86-1.05 (the mode rounds two Linear outputs per layer, literal O1 every matmul: independent errors of similar size)
+# residual_fp32 = 2 against its own restated regime, as a multiple of that regime's error against fp32. Measured (round 4): tiny 0.52, wide2 0.75-0.82, base 0.91-0.93
+# (mode 1 against `o1ops`: 0.64-0.78; every additional rounding point is a place where two correct implementations part, so the deeper stack sits higher).
+O1_OWN_BARS = {"tiny": 0.80, "wide2": 0.92, "base": 1.02}
 O1_LIT_BARS = {"tiny": (0.95, 1.15), "wide2": (0.95, 1.15), "base": (0.95, 1.15)}
 
 
@@ -111,7 +114,8 @@ def test_distance_to_the_operand_rounded_reference(golden, tag, name, residual_f
         e_lit, down = np.abs(lit - f32).mean(), np.abs(out - own)
         print(f"   mode 2: HIP-own-regime mean {down.mean():.3e} ({down.mean() / e_regime:.2f} x e_regime) | e_lit {e_lit:.3e}: HIP-fp32 / e_lit {d32.mean() / e_lit:.2f}, "
               f"HIP-o1lit / e_lit {dlit.mean() / e_lit:.2f} | own-regime vs fp32 {np.abs(own - f32).mean() / e_regime:.2f} x e_regime")
-        assert down.mean() <= (B + 0.07) * e_regime, (down.mean(), e_regime)        # as close to its own regime as a second correct implementation is
+        e_own = np.abs(own - f32).mean()  # the mode's own regime error (1.07-1.24 x e_regime: two more rounding points per layer than `o1ops`)
+        assert down.mean() <= O1_OWN_BARS[tag] * e_own, (down.mean(), e_own)        # as close to its own regime as a second correct implementation of it is
         assert d32.mean() <= O1_LIT_BARS[tag][0] * e_lit, (d32.mean(), e_lit)       # closer to fp32 than literal apex O1 itself is
         assert dlit.mean() <= O1_LIT_BARS[tag][1] * e_lit, (dlit.mean(), e_lit)     # and no further from the literal-O1 outputs than those are from fp32
         assert dlit.max() <= 4.0 * np.abs(lit - f32).max()
