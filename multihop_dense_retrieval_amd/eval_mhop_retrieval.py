@@ -240,7 +240,13 @@ def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, be
         dist.init_process_group(args.dist_backend)
     model.to(torch.device("cuda"))
     model.eval()
-    model.capture_on_first_use = True  # the loop repeats two shapes (B x max_q_len, B*beam x max_q_sp_len): their hipGraphs are captured at the first batch
+    model.capture_on_first_use = True  # the loop repeats two shapes (B x max_q_len, B*beam x max_q_sp_len); any other shape (a ragged last batch) is captured at its first batch
+    # ... and those two are captured here, as part of loading the model (typical fills: questions ~20 of 70 tokens, pairs ~60 % of 350)
+    # (the larger shape first: a lane's captures hold pointers into its workspace and are dropped when it grows)
+    model.precapture(args.batch_size * args.beam_size, args.max_q_sp_len, 0.6, lane=0)
+    model.precapture(args.batch_size, args.max_q_len, 0.3, lane=0)
+    if args.pipeline_batches:
+        model.precapture(args.batch_size, args.max_q_len, 0.3, lane=1)
 
     logger.info("Building index...")
     index = load_index(args.indexpath, d=bert_config.hidden_size, storage=args.index_storage)
