@@ -240,8 +240,8 @@ def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, be
         dist.init_process_group(args.dist_backend)
     model.to(torch.device("cuda"))
     model.eval()
-    model.capture_on_first_use = True  # the loop repeats two shapes (B x max_q_len, B*beam x max_q_sp_len); any other shape (a ragged last batch) is captured at its first batch
-    # ... and those two are captured here, as part of loading the model (typical fills: questions ~20 of 70 tokens, pairs ~60 % of 350)
+    # The loop repeats two shapes (B x max_q_len, B*beam x max_q_sp_len): their hipGraphs are captured here, as part of loading the model (typical fills:
+    # questions ~20 of 70 tokens, pairs ~60 % of 350). Any other shape (the ragged last batch) runs eagerly once: capturing it would cost more than it saves.
     # (the larger shape first: a lane's captures hold pointers into its workspace and are dropped when it grows)
     model.precapture(args.batch_size * args.beam_size, args.max_q_sp_len, 0.6, lane=0)
     model.precapture(args.batch_size, args.max_q_len, 0.3, lane=0)
