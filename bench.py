@@ -116,7 +116,7 @@ def parse():
     ap.add_argument("--questions", type=int, default=7405, help="--mode cli: questions in the synthetic qas file (HotpotQA dev has 7405)")
     ap.add_argument("--cli-dir", default=None, help="--mode cli: where the synthetic assets go (default: /dev/shm when it has room, else /tmp); removed afterwards")
     ap.add_argument("--cli-workers", type=int, default=16, help="--mode cli: the CLI's --num-workers (tokenizer worker processes; the flag's default is the reference's 10)")
-    ap.add_argument("--cli-legs", default="default,device", help="--mode cli: which flag sets to run: default = the reference's flags, device = --hop2-on-device --pipeline-batches")
+    ap.add_argument("--cli-legs", default="default,device", help="--mode cli: which flag sets to run: default = the reference's flags, device = --hop2-on-device, unfused = --no-pipeline-batches")
     ap.add_argument("--pool", type=int, default=16,
                     help="DIFFERENT question batches the timed steps cycle through (different lengths -> different hop-1 answers -> 19-22 k hop-2 tokens per batch "
                          "on the synthetic corpus); 1 = every step re-runs one batch (rounds 1-3)")
@@ -516,7 +516,7 @@ def cli_mode(args):
         assets = json.load(open(ready))
     result["config"]["assets_build_s"] = assets["build_seconds"]
     torch.cuda.empty_cache()
-    legs = {"default": [], "device": ["--hop2-on-device", "--pipeline-batches"]}
+    legs = {"default": [], "device": ["--hop2-on-device"], "unfused": ["--no-pipeline-batches"]}
     base = [assets["raw_data"], assets["indexpath"], assets["corpus_dict"], assets["model_path"], "--batch-size", str(B), "--beam-size", str(args.beam),
             "--topk", str(args.topk), "--shared-encoder", "--model-name", assets["model_name"], "--gpu", "--max-q-len", str(args.max_q_len),
             "--max-q-sp-len", str(args.max_q_sp_len), "--num-workers", str(args.cli_workers)]
@@ -547,9 +547,9 @@ def cli_mode(args):
                                         "steady_state_queries_per_s": steady, "whole_process_seconds": round(wall, 2), "records": sum(1 for _ in open(save)), "graph_captures": run["graph_captures"],
                                         "graph_replays": run["graph_replays"], "encoder_forward_calls": run["encoder_forward_calls"],
                                         "stats": {k: v for k, v in run["stats"].items() if k != "batch_done_t"}}
-        if rank == 0 and len(outs) == 2:
-            a, b = (open(p).read() for p in outs.values())
-            result["legs_jsonl_identical"] = a == b
+        if rank == 0 and len(outs) >= 2:
+            texts = [open(p).read() for p in outs.values()]
+            result["legs_jsonl_identical"] = all(t == texts[0] for t in texts[1:])
     finally:
         if world > 1:
             torch.distributed.barrier()

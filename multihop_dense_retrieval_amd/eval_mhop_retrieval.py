@@ -61,8 +61,10 @@ def build_parser():
     # extension (not in the reference): build the hop-2 inputs on the device from a token arena of the corpus
     # (tokenised once, cached next to the corpus dict) instead of host dict lookups + tokenizer between the hops
     p.add_argument("--hop2-on-device", action="store_true")
-    # extension: software-pipelined batch loop (hop 2 of batch i beside hop 1 of batch i+1; identical results)
-    p.add_argument("--pipeline-batches", action="store_true")
+    # extension: software-pipelined batch loop (hop 2 of batch i beside hop 1 of batch i+D as two concurrent forwards + ONE corpus pass; identical results)
+    p.add_argument("--pipeline-batches", action="store_true", help="(default since round 4; kept so that older command lines still parse)")
+    p.add_argument("--no-pipeline-batches", action="store_true",
+                   help="one corpus pass per hop and batch, hop-1 and hop-2 forwards one after the other (the fused form gives the same bytes of output)")
     # extension: batches in flight in the host/device software pipeline (pipeline.py; default: 2 with --hop2-on-device, else 4)
     p.add_argument("--inflight", type=int, default=None)
     # multi-GPU launches (torch.distributed.run): "nccl" is RCCL; gloo (+ --share-gpu: every rank on cuda:0) exists for the tests
@@ -245,7 +247,7 @@ def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, be
     # (the larger shape first: a lane's captures hold pointers into its workspace and are dropped when it grows)
     model.precapture(args.batch_size * args.beam_size, args.max_q_sp_len, 0.6, lane=0)
     model.precapture(args.batch_size, args.max_q_len, 0.3, lane=0)
-    if args.pipeline_batches:
+    if not args.no_pipeline_batches:
         model.precapture(args.batch_size, args.max_q_len, 0.3, lane=1)
 
     logger.info("Building index...")
@@ -278,7 +280,7 @@ def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, be
 
     pipe = TwoHopPipeline(model, index, pool, id2doc, finish_batch, batch_size=args.batch_size, beam=args.beam_size, max_q_len=args.max_q_len,
                           max_q_sp_len=args.max_q_sp_len, roberta=roberta, arena=arena, device=torch.device("cuda", torch.cuda.current_device()),
-                          rank=rank, world=world, depth=args.inflight, fuse=args.pipeline_batches, finish_pool=finish_pool)
+                          rank=rank, world=world, depth=args.inflight, fuse=not args.no_pipeline_batches, finish_pool=finish_pool)
 
     def fence():
         if world > 1:

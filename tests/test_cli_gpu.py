@@ -73,13 +73,13 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys, tiny_roberta_tokenizer):
                                                 "--topk", "4", "--model-name", str(cfg_dir), "--gpu", "--save-path", str(out2),
                                                 "--max-q-len", "12", "--max-q-sp-len", "40", "--hop2-on-device"], tokenizer=tok)
     assert out2.read_text() == out.read_text() and metrics2 == metrics
-    # --pipeline-batches (hop 2 of batch i beside hop 1 of batch i+1, one fused search per batch) must reproduce it too, on
+    # --no-pipeline-batches (one corpus pass per hop, forwards one after the other; the default fuses hop 2 of batch i with hop 1 of batch i+D) must reproduce it too, on
     # the host-tokenizer path and on the device-assembly path (23 questions in batches of 10: a ragged last batch)
     for extra in ([], ["--hop2-on-device"]):
         out6 = tmp_path / ("paths_pipe%d.jsonl" % len(extra))
         metrics6, _ = eval_mhop_retrieval.main([str(data), path, str(save / "id2doc.json"), str(ckpt), "--num-workers", "0", "--batch-size", "10", "--beam-size", "3",
                                                 "--topk", "4", "--model-name", str(cfg_dir), "--gpu", "--save-path", str(out6),
-                                                "--max-q-len", "12", "--max-q-sp-len", "40", "--pipeline-batches"] + extra, tokenizer=tok)
+                                                "--max-q-len", "12", "--max-q-sp-len", "40", "--no-pipeline-batches"] + extra, tokenizer=tok)
         assert out6.read_text() == out.read_text() and metrics6 == metrics
     rec = json.loads(lines[0])
     assert list(rec.keys()) == ["_id", "question", "candidate_chains"] and rec["question"].endswith("?")

@@ -54,7 +54,7 @@ def cli_args(a, out, extra):
             "--save-path", str(out), "--max-q-len", "12", "--max-q-sp-len", "40"] + extra
 
 
-@pytest.mark.parametrize("extra", [[], ["--hop2-on-device", "--pipeline-batches"]], ids=["default", "device+fused"])
+@pytest.mark.parametrize("extra", [[], ["--hop2-on-device", "--no-pipeline-batches"]], ids=["default", "device+unfused"])
 def test_one_rank_pipeline_variants_agree(toy_assets, extra):
     """Worker processes / in-flight depth / fusion do not change a byte of the output (one rank)."""
     from multihop_dense_retrieval_amd import eval_mhop_retrieval
@@ -69,8 +69,8 @@ def test_one_rank_pipeline_variants_agree(toy_assets, extra):
     assert run["questions"] == 57 and run["stats"]["batches"] == 6 and run["encoder_forward_calls"] == 12
 
 
-@pytest.mark.parametrize("world,port,extra", [(2, 29591, []), (8, 29592, ["--hop2-on-device"]), (2, 29593, ["--hop2-on-device", "--pipeline-batches"])],
-                         ids=["w2-default", "w8-device", "w2-device+fused"])
+@pytest.mark.parametrize("world,port,extra", [(2, 29591, []), (8, 29592, ["--hop2-on-device"]), (2, 29593, ["--hop2-on-device", "--no-pipeline-batches"])],
+                         ids=["w2-default", "w8-device", "w2-device+unfused"])
 def test_question_partitioned_cli_is_byte_identical_to_one_rank(toy_assets, world, port, extra):
     from multihop_dense_retrieval_amd import eval_mhop_retrieval
     a = toy_assets
