@@ -255,3 +255,30 @@ def test_int8_screen_bound_is_rigorous():
         q8u, tu = quant(q)
         bound_u = tu[:, None] * su[None, :] * (0.5 * np.abs(q8u).sum(1)[:, None] + 0.5 * np.abs(x8u).sum(1)[None, :] + 0.25 * d)
         assert np.median(bound_u) > 3.0 * np.median(bound), (name, np.median(bound_u), np.median(bound))
+
+
+def test_arena_cache_is_rebuilt_when_its_tokenisation_rule_differs(tmp_path, tiny_roberta_tokenizer):
+    """<corpus_dict>.arena.npz carries a tag (tokenisation rule, tokenizer class, vocabulary hash, empty-text rule, token cap); a cache written
+    under another tag -- or by a revision that wrote no tag -- loads as None, so the CLI rebuilds it instead of mixing two rules in one hop-2 input."""
+    import numpy as np
+    from multihop_dense_retrieval_amd import data
+    from multihop_dense_retrieval_amd.arena import TokenArena, arena_tag
+    tok = tiny_roberta_tokenizer
+    id2doc = {"0": {"title": "T0", "text": "the title and text"}, "1": {"title": "the born", "text": "  "}}
+    a = TokenArena.from_corpus(id2doc, tok, roberta=True, max_tokens=40)
+    tag = arena_tag(tok, True, 40)
+    path = str(tmp_path / "c.json.arena.npz")
+    a.save(path, tag=tag)
+    b = TokenArena.load(path, expect_tag=tag)
+    assert b is not None and np.array_equal(b.tokens.numpy(), a.tokens.numpy()) and np.array_equal(b.offsets.numpy(), a.offsets.numpy()) and b.empty.tolist() == [0, 1]
+    assert TokenArena.load(path, expect_tag=arena_tag(tok, True, 350)) is None          # another token cap
+    assert TokenArena.load(path, expect_tag=arena_tag(tok, False, 40)) is None          # another empty-text rule
+    old = data.PREFIX_SPACE_2_11
+    try:
+        data.PREFIX_SPACE_2_11 = False
+        assert arena_tag(tok, True, 40) != tag and TokenArena.load(path, expect_tag=arena_tag(tok, True, 40)) is None  # the rule ADVICE r3 named
+    finally:
+        data.PREFIX_SPACE_2_11 = old
+    np.savez(str(tmp_path / "old.npz"), tokens=a.tokens.numpy(), offsets=a.offsets.numpy(), empty=a.empty.numpy())  # a cache of round 3: no tag
+    assert TokenArena.load(str(tmp_path / "old.npz"), expect_tag=tag) is None
+    assert TokenArena.load(str(tmp_path / "old.npz")) is not None  # (explicit loads without a tag still work)
