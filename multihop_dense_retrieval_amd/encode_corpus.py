@@ -124,7 +124,9 @@ class DeviceStager:
         out = dict(rest)
         for (k, v), o in zip(items, offs):
             nb = v.numel() * v.element_size()
-            host[o:o + nb].view(v.dtype).view(v.shape).copy_(v)
+            # numpy's memcpy: torch's CPU copy_ forks its intra-op thread pool (256 threads on the MI355X hosts) for a copy of this size and waits for
+            # cores the DataLoader workers occupy -- 3-4 ms per 280 KB measured in the eval CLI (pipeline.py)
+            np.copyto(host[o:o + nb].view(v.dtype).view(v.shape).numpy(), v.detach().contiguous().numpy())
             out[k] = dev[o:o + nb].view(v.dtype).view(v.shape)
         dev[:total].copy_(host[:total], non_blocking=True)
         self.ev[j] = torch.cuda.Event()
