@@ -30,6 +30,8 @@ q = torch.randn((130, 768), generator=g, device=dev)
 for k in (1, 8):
     D, I = sidx.local.search_device(q, k)
     Dm, Im = sidx.search_gathered(D, I, force=True)  # all_gather of the packed int64 buffer + mdr_topk_merge
+    Dp, Ip = sidx.search_device(q, k, force=True)    # round 4's exchange: search -> packed block, one RCCL all-gather of uint8 blocks, mdr_topk_merge_packed
+    assert torch.equal(Ip, Im) and torch.equal(Dp, Dm), "packed exchange differs from the generic one"
     assert torch.equal(Dm, D) and torch.equal(Im, I), k
     # the faiss-style numpy surface over the same collective: host queries in, host results out (this used to hand
     # CPU tensors to the nccl group and to the HIP merge kernel)
