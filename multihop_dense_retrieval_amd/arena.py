@@ -49,17 +49,21 @@ class TokenArena:
         pre = prefix_space_2_11 if is_roberta_family(tokenizer) else (lambda t: t)
         n = len(id2doc)
         toks, offs, empty = [], np.zeros(n + 1, np.int64), np.zeros(n, np.uint8)
-        for i in range(n):
-            doc = id2doc[str(i)]
-            text = doc["text"]
-            if roberta and text.strip() == "":
-                text = doc["title"]
-                empty[i] = 1
-            ids = tokenizer(pre(text), add_special_tokens=False)["input_ids"]
-            if max_tokens is not None:
-                ids = ids[:max_tokens]  # never more than max_q_sp_len - 4 tokens can survive truncation
-            toks.append(np.asarray(ids, np.int32))
-            offs[i + 1] = offs[i] + len(ids)
+        step = 4096  # one tokenizer call per block of passages: the fast tokenizers encode a batch in parallel (5 M passages: minutes instead of an hour)
+        for lo in range(0, n, step):
+            texts = []
+            for i in range(lo, min(n, lo + step)):
+                doc = id2doc[str(i)]
+                text = doc["text"]
+                if roberta and text.strip() == "":
+                    text = doc["title"]
+                    empty[i] = 1
+                texts.append(pre(text))
+            for j, ids in enumerate(tokenizer(texts, add_special_tokens=False)["input_ids"]):
+                if max_tokens is not None:
+                    ids = ids[:max_tokens]  # never more than max_q_sp_len - 4 tokens can survive truncation
+                toks.append(np.asarray(ids, np.int32))
+                offs[lo + j + 1] = offs[lo + j] + len(ids)
         tokens = np.concatenate(toks) if toks else np.zeros(0, np.int32)
         return cls(torch.from_numpy(tokens), torch.from_numpy(offs), torch.from_numpy(empty))
 
