@@ -58,7 +58,9 @@ def test_arena_from_corpus_and_roundtrip(tmp_path):
     from multihop_dense_retrieval_amd.arena import TokenArena
 
     class Tok:
-        def __call__(self, text, add_special_tokens=False):
+        def __call__(self, text, add_special_tokens=False):  # a text or, like the HF tokenizers, a batch of texts
+            if isinstance(text, (list, tuple)):
+                return {"input_ids": [[3 + len(w) for w in t.split()] for t in text]}
             return {"input_ids": [3 + len(w) for w in text.split()]}
     id2doc = {"0": {"title": "A b", "text": "x yy zzz"}, "1": {"title": "Only title here", "text": "  "}, "2": {"title": "T", "text": "q"}}
     a = TokenArena.from_corpus(id2doc, Tok())
