@@ -150,14 +150,12 @@ class TokenizerPool:
 # the pipeline
 # ------------------------------------------------------------------------------------------------------
 class _Job:
-    __slots__ = ("idx", "lo", "hi", "n", "questions", "ann", "tok1", "tok2", "q_ids", "q_mask", "D", "I", "D_host", "I_host", "e1", "host", "e2",
-                 "result", "q_emb")
+    __slots__ = ("idx", "lo", "hi", "n", "questions", "ann", "tok1", "q_ids", "q_mask", "D", "I", "D_host", "I_host", "e1", "host", "e2", "result")
 
     def __init__(self, idx, lo, hi, questions, ann):
         self.idx, self.lo, self.hi, self.n = idx, lo, hi, hi - lo
         self.questions, self.ann = questions, ann
-        self.tok1 = self.tok2 = self.q_ids = self.q_mask = self.D = self.I = self.D_host = self.I_host = self.e1 = self.host = self.e2 = None
-        self.result = self.q_emb = None
+        self.tok1 = self.q_ids = self.q_mask = self.D = self.I = self.D_host = self.I_host = self.e1 = self.host = self.e2 = self.result = None
 
 
 class TwoHopPipeline:
