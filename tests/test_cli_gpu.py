@@ -139,3 +139,37 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys, tiny_roberta_tokenizer):
     best3 = set(np.argsort(-scores)[:3].tolist())
     got_hop1 = {c[0]["title"] for c in rec["candidate_chains"]}
     assert got_hop1 <= {f"T{i}" for i in best3} | {f"T{i}" for i in np.argsort(-scores)[:5].tolist()}
+    # ... and the WHOLE run against the reference loop recomputed with the oracle (eval_mhop_retrieval.py:142-206 on the saved index: fp64 restatement of the
+    # encoder, exact inner products, the reference's own pair construction and path ranking -- oracle/mhop_oracle.py's expressions via mhop.rank_paths).
+    # The HIP encoder's embeddings differ from the fp64 ones by fp16-operand noise, so a chain may differ where two path scores are closer than that noise:
+    # every question's best chain must be the oracle's best chain or lose to it by less than the noise, and most questions must agree on all four chains.
+    from multihop_dense_retrieval_amd import mhop
+    id2doc_n = mhop.load_corpus_dict(str(save / "id2doc.json"))
+    xb64 = xb.astype(np.float64)
+    agree_all, agree_top, worst_gap = 0, 0, 0.0
+    for qi, q in enumerate(qs):
+        qtext = mhop.strip_question(q["question"])
+        i1, m1 = encode_np(tok, qtext, None, 12, True)
+        s1 = xb64 @ roberta_oracle.encode(sd, geom, i1, m1, np.float64)[0]
+        I1 = np.argsort(-s1, kind="stable")[:3]
+        D1 = s1[I1].copy()
+        D2, I2 = np.zeros((3, 3)), np.zeros((3, 3), np.int64)
+        for j, doc in enumerate(I1):
+            text = id2doc_n[str(int(doc))]["text"]
+            if not text.strip():
+                text, D1[j] = id2doc_n[str(int(doc))]["title"], -np.inf
+            i2, m2 = encode_np(tok, qtext, text, 40, True)
+            s2 = xb64 @ roberta_oracle.encode(sd, geom, i2, m2, np.float64)[0]
+            I2[j] = np.argsort(-s2, kind="stable")[:3]
+            D2[j] = s2[I2[j]]
+        want = mhop.rank_paths(D1[None], I1[None], D2.reshape(1, 9), I2.reshape(1, 9), 3, 4)[0]
+        got = [(c[0]["title"], c[1]["title"]) for c in json.loads(lines[qi])["candidate_chains"]]
+        want_t = [(f"T{h1}", f"T{h2}") for h1, h2, _ in want]
+        agree_all += got == want_t
+        agree_top += got[0] == want_t[0]
+        if got[0] != want_t[0]:  # the oracle's score of the chain the CLI ranked first, against the oracle's best
+            score = {t: sc for t, (_, _, sc) in zip(want_t, want)}
+            all_paths = {(f"T{int(I1[a])}", f"T{int(I2[a, b])}"): D1[a] + D2[a, b] for a in range(3) for b in range(3)}
+            worst_gap = max(worst_gap, want[0][2] - all_paths.get(got[0], -np.inf))
+    print(f"CLI vs oracle loop on 23 questions: best chain equal {agree_top}, all four chains equal {agree_all}, worst oracle-score gap of a differing best chain {worst_gap:.2e}")
+    assert agree_top >= 20 and agree_all >= 14 and worst_gap <= 0.15  # (path scores are ~1e2; fp16-operand noise on them ~1e-1 for this closely packed toy corpus)
