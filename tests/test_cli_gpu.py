@@ -172,4 +172,4 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys, tiny_roberta_tokenizer):
             all_paths = {(f"T{int(I1[a])}", f"T{int(I2[a, b])}"): D1[a] + D2[a, b] for a in range(3) for b in range(3)}
             worst_gap = max(worst_gap, want[0][2] - all_paths.get(got[0], -np.inf))
     print(f"CLI vs oracle loop on 23 questions: best chain equal {agree_top}, all four chains equal {agree_all}, worst oracle-score gap of a differing best chain {worst_gap:.2e}")
-    assert agree_top >= 20 and agree_all >= 14 and worst_gap <= 0.15  # (path scores are ~1e2; fp16-operand noise on them ~1e-1 for this closely packed toy corpus)
+    assert agree_top >= 22 and agree_all >= 20 and worst_gap <= 0.15  # measured: 23 / 23 / 0 (path scores are ~1e2; fp16-operand noise could swap near-ties of this closely packed toy corpus)
