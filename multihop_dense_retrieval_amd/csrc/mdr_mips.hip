@@ -539,7 +539,9 @@ int run_screenk(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
     return MDR_OK;
 }
 
-// 2 <= k <= 128 with more than 128 queries: groups of 256 on the 32-queries-per-wave kernels
+// 2 <= k <= 256 with more than 128 queries: groups of 256 on the 32-queries-per-wave kernels. A LAST group of at most 128 queries (nq = 800: 3 x 256 + 32)
+// goes through the 16-queries-per-wave kernels instead (round 4): a pass of theirs is HBM-bound on the hi plane (1.6 ms at 5 M rows), a 32-queries-per-wave
+// pass costs its MFMA skeleton whatever the number of queries (2.15 ms). Query fragments, bounds, lists and outputs have the same layout for both.
 template <bool BF>
 int run_screenk32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, int k, const char* qhi, float* D_dev, long long* I_dev,
                   long long id_offset, hipStream_t st) {
@@ -548,6 +550,8 @@ int run_screenk32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_de
     const size_t merge_lds = (size_t)kMergeKLds * 8;
     int rc_ = ensure_dynamic_lds((const void*)mips_screen32_kernel<NKB, 2, BF>, (int)lds_bytes);
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screenk32_kernel<NKB, BF>, (int)lds_bytes);
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen_kernel<NKB, 2, BF>, (int)lds_bytes);
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screenk_kernel<NKB, BF>, (int)lds_bytes);
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)merge_screenk_kernel<BF>, (int)merge_lds);
     if (rc_) return rc_;
     float* bound = (float*)(ws + p.off_bound);
@@ -566,16 +570,26 @@ int run_screenk32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_de
         const char* qg = qhi + gi * qgroup_bytes;
         const float* bg = bound + (size_t)gi * kWideQ;
         float* tg = tau0 + (size_t)gi * kWideQ;
-        MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * kWideQ * 4, st));
-        MDR_HIP_TRY(hipMemsetAsync(wgmax, 0, (size_t)p.G * stages * kWideQ * 4, st));
-        hipLaunchKernelGGL((mips_screen32_kernel<NKB, 2, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg, nqg,
-                           gi * kWideQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, stages);
-        hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G * stages, k, tg, kWideQ);
-        hipLaunchKernelGGL((mips_screenk32_kernel<NKB, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg,
-                           (const float*)tg, nqg, cand, cnt, k, sctl);
+        const bool narrow = ngroups > 1 && gi == ngroups - 1 && nqg <= kStreamQ;  // the remainder group: 16 queries per wave, list stride kStreamQ
+        const int qcap = narrow ? kStreamQ : kWideQ;
+        MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * qcap * 4, st));
+        MDR_HIP_TRY(hipMemsetAsync(wgmax, 0, (size_t)p.G * stages * qcap * 4, st));
+        if (narrow) {
+            hipLaunchKernelGGL((mips_screen_kernel<NKB, 2, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg, nqg,
+                               gi * kWideQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, stages);
+            hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G * stages, k, tg, qcap);
+            hipLaunchKernelGGL((mips_screenk_kernel<NKB, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg,
+                               (const float*)tg, nqg, cand, cnt, k, sctl);
+        } else {
+            hipLaunchKernelGGL((mips_screen32_kernel<NKB, 2, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg, nqg,
+                               gi * kWideQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, stages);
+            hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G * stages, k, tg, qcap);
+            hipLaunchKernelGGL((mips_screenk32_kernel<NKB, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg,
+                               (const float*)tg, nqg, cand, cnt, k, sctl);
+        }
         hipLaunchKernelGGL((merge_screenk_kernel<BF>), dim3(nqg), dim3(256), merge_lds, st, (const u64*)cand, (const int*)cnt, p.G, k, bg, (const char*)h->hi,
                            (const char*)h->lo, h->nkb, q_dev + (size_t)gi * kWideQ * h->d, D_dev + (size_t)gi * kWideQ * k,
-                           I_dev + (size_t)gi * kWideQ * k, id_offset, sctl, kWideQ, row_unscale(h));
+                           I_dev + (size_t)gi * kWideQ * k, id_offset, sctl, qcap, row_unscale(h));
         MDR_HIP_TRY(hipGetLastError());
     }
     return MDR_OK;
