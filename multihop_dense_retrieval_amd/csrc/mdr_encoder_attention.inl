@@ -364,8 +364,18 @@ __global__ void __launch_bounds__(64) attention_cls_kernel(const _Float16* __res
     __syncthreads();
     const float inv = 1.f / sum;
     float o = 0.f;
-    for (int key = 0; key < len; ++key)  // P rounded to fp16 like the MFMA path (apex O1: probs enter the PV matmul as fp16)
-        o = fmaf((float)(_Float16)(p_s[key] * inv), (float)qkv[(size_t)(start + key) * H3 + 2 * H + h * 64 + lane], o);
+    // P rounded to fp16 like the MFMA path (apex O1: probs enter the PV matmul as fp16). Eight V rows are fetched before they are summed -- IN KEY ORDER, so the
+    // result has the bits of the plain loop: one dependent global load per key was 50 us for the hop-2 batch (200 keys x a memory round trip).
+    const _Float16* vp = qkv + (size_t)start * H3 + 2 * H + h * 64 + lane;
+    int key = 0;
+    for (; key + 8 <= len; key += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)vp[(size_t)(key + j) * H3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o = fmaf((float)(_Float16)(p_s[key + j] * inv), v[j], o);
+    }
+    for (; key < len; ++key) o = fmaf((float)(_Float16)(p_s[key] * inv), (float)vp[(size_t)key * H3], o);
     ctx_cls[(size_t)b * H + h * 64 + lane] = (_Float16)o;
 }
 
