@@ -2,6 +2,7 @@
  * include/mdr_hip_measure.h -- hooks of MEASUREMENT builds of libmdrhip (variant libraries built next to the product one with
  *     python -m multihop_dense_retrieval_amd.build -DMDR_GEMM_ABL=5 --out=libmdrhip_gemm_timeline.so
  *     python -m multihop_dense_retrieval_amd.build -DMDR_I8_ABL=9  --out=libmdrhip_i8_timeline.so
+ *     python -m multihop_dense_retrieval_amd.build -DMDR_ATTN_ABL=9 --out=libmdrhip_attn_timeline.so
  * and loaded by the measurement scripts through MDR_LIB_PATH). The product library (no -D) exports none of these, holds no
  * timeline globals and none of the ablation code paths: every MDR_*_ABL switch is a compile-time macro, because several of them
  * produce WRONG results by design (they remove one pipe's work to see what a kernel waits for).
@@ -23,6 +24,12 @@ int mdr_test_gemm_stamps(unsigned long long* out8_host, int reset);
 /* -DMDR_I8_ABL=9 builds: the same kind of timeline for the 32-queries-per-wave int8 screen kernel ([0] wait + barrier,
  * [1] exchange + DMA issue, [2] MFMA chain, [3] epilogue, [4] bound sharing, [7] stages). (scripts/gpu_i8_quick.py) */
 int mdr_test_i8_stamps(unsigned long long* out8_host, int reset);
+
+/* -DMDR_ATTN_ABL=9 builds: per-workgroup timeline of the LAST attention_stream_kernel launch, 8 words per workgroup
+ * (linear id (z * B + b) * heads + h): wall_clock64 (100 MHz, chip-wide) at [0] entry, [1] first K/V chunk landed, [2] first query block
+ * stored, [3] exit; [4] sequence length (0: the workgroup left at once), [5] HW_ID, [6] XCC_ID. Results of that build are correct.
+ * (scripts/gpu_attn_timeline.py) */
+int mdr_test_attn_stamps(unsigned long long* out_host, int max_wgs);
 
 #ifdef __cplusplus
 }

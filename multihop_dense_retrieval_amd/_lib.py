@@ -70,6 +70,7 @@ _SIGNATURES = {
 _MEASURE_SIGNATURES = {
     "mdr_test_gemm_stamps": (_c.c_int, [_c.POINTER(_c.c_uint64), _c.c_int]),
     "mdr_test_i8_stamps": (_c.c_int, [_c.POINTER(_c.c_uint64), _c.c_int]),
+    "mdr_test_attn_stamps": (_c.c_int, [_c.POINTER(_c.c_uint64), _c.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -392,6 +392,15 @@ int mdr_test_gemm_stamps(unsigned long long* out8_host, int reset) {
 }
 #endif
 
+#if MDR_ATTN_ABL == 9  // measurement builds only (include/mdr_hip_measure.h)
+int mdr_test_attn_stamps(unsigned long long* out_host, int max_wgs) {
+    MDR_REQUIRE(out_host && max_wgs > 0 && max_wgs <= kAttnStampWgs, "NULL pointer or max_wgs out of range");
+    MDR_HIP_TRY(hipDeviceSynchronize());
+    MDR_HIP_TRY(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_attn_stamp), (size_t)max_wgs * 8 * sizeof(unsigned long long)));
+    return MDR_OK;
+}
+#endif
+
 int mdr_encoder_set_fill_hint(mdr_encoder* h, float fill) {
     MDR_REQUIRE(h != nullptr, "encoder handle is NULL");
     MDR_REQUIRE(fill >= 0.f && fill <= 1.f, "fill must be in [0, 1] (0 = unknown)");

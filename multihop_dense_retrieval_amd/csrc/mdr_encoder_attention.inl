@@ -151,9 +151,17 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #define MDR_ATTN_FORCE 0
 #endif
 // measurement builds (wrong results; scripts/gpu_attn_ab.sh): 1 no K fragment reads, 2 no V fragment reads, 3 neither, 4 staging only
-// (Q loads, K/V DMA, barrier, context stores), 5 no exp, 6 = 4 with K only, 7 = 4 without the stores, 8 = 4 with one row per DMA piece
+// (Q loads, K/V DMA, barrier, context stores), 5 no exp, 6 = 4 with K only, 7 = 4 without the stores, 8 = 4 with one row per DMA piece;
+// 9 = correct results + a per-workgroup timeline (g_attn_stamp, scripts/gpu_attn_timeline.py)
 #ifndef MDR_ATTN_ABL
 #define MDR_ATTN_ABL 0
+#endif
+#if MDR_ATTN_ABL == 9  // timeline build (include/mdr_hip_measure.h: mdr_test_attn_stamps; results are correct)
+constexpr int kAttnStampWgs = 4096;
+__device__ unsigned long long g_attn_stamp[kAttnStampWgs * 8];  // per workgroup: wall_clock64 at entry / K,V landed / first query block done / exit, len, HW_ID, XCC_ID
+#define MDR_ATTN_STAMP(slot) do { if (tid == 0 && wg_lin < kAttnStampWgs) g_attn_stamp[wg_lin * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define MDR_ATTN_STAMP(slot) do { } while (0)
 #endif
 template <int NTC>  // key tiles of 16 per chunk
 __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
@@ -166,6 +174,14 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, lr = lane & 15;
     const int h = blockIdx.x, b = blockIdx.y;
+#if MDR_ATTN_ABL == 9
+    const int wg_lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tid == 0 && wg_lin < kAttnStampWgs) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_attn_stamp[wg_lin * 8 + i] = 0;
+    }
+    MDR_ATTN_STAMP(0);
+#endif
     const int start = cu[b], len = cu[b + 1] - start;
     const int qb0 = blockIdx.z * 128;
     if (qb0 >= len) return;
@@ -173,6 +189,16 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
     // are staged once and the second block of 128 queries runs over the same image (MDR_ATTN_MERGE=0 builds: one workgroup per block).
     const bool merged = MDR_ATTN_MERGE && len <= KC && len > 128;
     if (merged && blockIdx.z > 0) return;
+#if MDR_ATTN_ABL == 9
+    if (tid == 0 && wg_lin < kAttnStampWgs) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_attn_stamp[wg_lin * 8 + 4] = (unsigned long long)len;
+        g_attn_stamp[wg_lin * 8 + 5] = hw;
+        g_attn_stamp[wg_lin * 8 + 6] = xcc;
+    }
+#endif
     const int nsub = merged ? 2 : 1;
     const int H3 = 3 * H;
 
@@ -230,8 +256,9 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
 #pragma unroll
             for (int ds = 0; ds < 2; ++ds) asm volatile("" : "+v"(qf[ds]));
             __syncthreads();
+            if (kc0 == 0) MDR_ATTN_STAMP(1);
         }
-        if (MDR_ATTN_ABL == 4 || MDR_ATTN_ABL >= 6) continue;
+        if (MDR_ATTN_ABL == 4 || (MDR_ATTN_ABL >= 6 && MDR_ATTN_ABL <= 8)) continue;
         if (!wave_valid) continue;
 
         // ---- S^T tiles of this chunk: lane holds keys kc0 + 16 t + 4 g + r for query lr
@@ -323,7 +350,9 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
             *(half4*)(ctx + (size_t)(start + qi) * H + h * 64 + dt * 16 + 4 * g) = w;
         }
     }
+    if (sub == 0) MDR_ATTN_STAMP(2);
     }  // sub
+    MDR_ATTN_STAMP(3);
 }
 
 // Last layer: only the CLS row of each sequence feeds the projection head, so its attention needs ONE query per
