@@ -42,11 +42,11 @@ def test_product_library_holds_no_measurement_code():
     lib = ctypes.CDLL(path)
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mdr_hip_measure.h")).read(), flags=re.S)
     hooks = sorted(set(re.findall(r"\b(mdr_[a-z0-9_]+)\s*\(", text)))
-    assert hooks == ["mdr_test_gemm_stamps", "mdr_test_i8_stamps"]
+    assert hooks == ["mdr_test_attn_stamps", "mdr_test_gemm_stamps", "mdr_test_i8_stamps"]
     for name in hooks:
         assert not hasattr(lib, name), f"{name} is a measurement hook but the product library exports it"
     blob = open(path, "rb").read()
-    for knob in (b"MDR_GEMM_ABL", b"MDR_GEMM_EPI", b"MDR_I8_ABL", b"MDR_ATTN_ABL", b"g_gemm_stamp", b"g_i8_stamp"):
+    for knob in (b"MDR_GEMM_ABL", b"MDR_GEMM_EPI", b"MDR_I8_ABL", b"MDR_ATTN_ABL", b"g_gemm_stamp", b"g_i8_stamp", b"g_attn_stamp"):
         assert knob not in blob, f"{knob!r} found in the product library"
     allowed = {"MDR_GEMM_CFG", "MDR_MIPS_WIDE", "MDR_MIPS_I8"}
     seen = set()
