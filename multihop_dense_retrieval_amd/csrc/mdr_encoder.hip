@@ -233,7 +233,7 @@ int launch_attention_stream(const _Float16* qkv, const int* cu, int B, int L, in
     constexpr int lds = NTC * 16 * 128 * 2;
     { int rc_ = ensure_dynamic_lds((const void*)attention_stream_kernel<NTC>, lds); if (rc_) return rc_; }
     dim3 grid(heads, B, (L + 127) / 128);
-    hipLaunchKernelGGL((attention_stream_kernel<NTC>), grid, dim3(512), lds, st, qkv, cu, H, ctx);
+    hipLaunchKernelGGL((attention_stream_kernel<NTC>), grid, dim3(kAttnThreads), lds, st, qkv, cu, H, ctx);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }

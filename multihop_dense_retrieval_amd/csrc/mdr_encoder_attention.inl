@@ -163,11 +163,20 @@ __device__ unsigned long long g_attn_stamp[kAttnStampWgs * 8];  // per workgroup
 #else
 #define MDR_ATTN_STAMP(slot) do { } while (0)
 #endif
+// MDR_ATTN_QH = 2 (measurement builds): 32 queries per wave -- a workgroup of FOUR waves serves the block of 128 queries, every K / V fragment read feeds
+// two 16-query MFMA chains, and a wave may use 256 registers (still two workgroups per CU). The form VERDICT r3 listed as untried.
+#ifndef MDR_ATTN_QH
+#define MDR_ATTN_QH 1
+#endif
+constexpr int kAttnQH = MDR_ATTN_QH, kAttnWaves = 8 / kAttnQH, kAttnThreads = 64 * kAttnWaves;
 template <int NTC>  // key tiles of 16 per chunk
-__global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
-                                                               _Float16* __restrict__ ctx) {
+__global__ void __launch_bounds__(kAttnThreads)
+#if MDR_ATTN_QH == 2
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+attention_stream_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H, _Float16* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int KC = NTC * 16;
+    constexpr int KC = NTC * 16, QH = kAttnQH, W = kAttnWaves;
     char* Ks = lds;              // [KC][64] halfs, 128-B rows
     char* Vs = lds + KC * 128;   // same
     const int tid = threadIdx.x, lane = tid & 63;
@@ -219,24 +228,29 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
     // same vmcnt(0) wait, so that Q, K and V travel together (one memory round trip instead of two: round 2 waited for Q first, and the
     // staging chain -- cu[b], Q, K/V, barrier -- was 33 of the kernel's 47 us). The second query block of a merged pair is fetched into
     // the same registers as soon as the first block's S tiles no longer need them, under that block's softmax and PV product.
-    half8 qf[2];
+    half8 qf[QH][2];
     auto load_q = [&](int sub_) __attribute__((always_inline)) {
-        const int qi_ = qb0 + sub_ * 128 + wave * 16 + lr;
-        const int qrow_ = qi_ < len ? qi_ : len - 1;
 #pragma unroll
-        for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const half8*)(qkv + (size_t)(start + qrow_) * H3 + h * 64 + ds * 32 + g * 8);
+        for (int qh = 0; qh < QH; ++qh) {
+            const int qi_ = qb0 + sub_ * 128 + (wave * QH + qh) * 16 + lr;
+            const int qrow_ = qi_ < len ? qi_ : len - 1;
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) qf[qh][ds] = *(const half8*)(qkv + (size_t)(start + qrow_) * H3 + h * 64 + ds * 32 + g * 8);
+        }
     };
     load_q(0);
     for (int sub = 0; sub < nsub; ++sub) {
-    const int q0 = qb0 + sub * 128 + wave * 16;
+    const int q0 = qb0 + sub * 128 + wave * QH * 16;
     const bool wave_valid = q0 < len;  // waves past the sequence only help staging
-    const int qi = q0 + lr;
-    const bool qvalid = qi < len;
 
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x4 o[4];
+    float m_run[QH], l_run[QH];
+    f32x4 o[QH][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int qh = 0; qh < QH; ++qh) {
+        m_run[qh] = -INFINITY; l_run[qh] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qh][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int kc0 = 0; kc0 < len; kc0 += KC) {
         const int ck = min(KC, len - kc0);     // keys of this chunk
@@ -245,7 +259,7 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
         if (sub == 0) {                        // (the second block of a merged pair finds its single chunk staged)
             if (kc0 > 0) __syncthreads();      // every wave is done reading the previous chunk
             // ---- stage K and V rows kc0 .. kc0 + 32 np - 1 (clamped to len - 1)
-            for (int i = wave; i < np * 4; i += 8) {
+            for (int i = wave; i < np * 4; i += W) {
                 int row = kc0 + i * 8 + (MDR_ATTN_ABL == 8 ? 0 : st_row);
                 row = row < len ? row : len - 1;
                 const _Float16* src = qkv + (size_t)(start + row) * H3 + H + h * 64 + st_col;
@@ -254,7 +268,9 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K / V pieces AND (first chunk) the Q loads issued in front of them
 #pragma unroll
-            for (int ds = 0; ds < 2; ++ds) asm volatile("" : "+v"(qf[ds]));
+            for (int qh = 0; qh < QH; ++qh)
+#pragma unroll
+                for (int ds = 0; ds < 2; ++ds) asm volatile("" : "+v"(qf[qh][ds]));
             __syncthreads();
             if (kc0 == 0) MDR_ATTN_STAMP(1);
         }
@@ -262,92 +278,115 @@ __global__ void __launch_bounds__(512) attention_stream_kernel(const _Float16* _
         if (!wave_valid) continue;
 
         // ---- S^T tiles of this chunk: lane holds keys kc0 + 16 t + 4 g + r for query lr
-        f32x4 s[NTC];
-        float cmax = -INFINITY;
+        f32x4 s[QH][NTC];
+        float cmax[QH];
+#pragma unroll
+        for (int qh = 0; qh < QH; ++qh) cmax[qh] = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NTC; ++t) {
-            s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int qh = 0; qh < QH; ++qh) s[qh][t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             if (t < nt) {
                 half8 k0, k1;
-                if (MDR_ATTN_ABL == 1 || MDR_ATTN_ABL == 3) { k0 = qf[1]; k1 = qf[0]; }
+                if (MDR_ATTN_ABL == 1 || MDR_ATTN_ABL == 3) { k0 = qf[0][1]; k1 = qf[0][0]; }
                 else {
                     k0 = *(const half8*)(Ks + k_rd + t * 2048 + ksw0);
                     k1 = *(const half8*)(Ks + k_rd + t * 2048 + ksw1);
                 }
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], acc, 0, 0, 0);
-                acc *= 0.125f;
-                if (t == nt - 1) {  // only the chunk's last tile can hold keys past the sequence (clamped copies of its last row)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (kc0 + t * 16 + 4 * g + r >= len) acc[r] = -INFINITY;
+                for (int qh = 0; qh < QH; ++qh) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[qh][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[qh][1], acc, 0, 0, 0);
+                    acc *= 0.125f;
+                    if (t == nt - 1) {  // only the chunk's last tile can hold keys past the sequence (clamped copies of its last row)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kc0 + t * 16 + 4 * g + r >= len) acc[r] = -INFINITY;
+                    }
+                    s[qh][t] = acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cmax[qh] = fmaxf(cmax[qh], acc[r]);
                 }
-                s[t] = acc;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, acc[r]);
             }
         }
         if (merged && sub == 0) load_q(1);  // (merged: one chunk) the next block's Q, under this block's softmax and PV product
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-        const float m_new = fmaxf(m_run, cmax);  // finite: every chunk holds at least one valid key
-        const float alpha = exp2f((m_run - m_new) * 1.4426950408889634f);  // 0 on the first chunk
-        const float mb = -m_new * 1.4426950408889634f;
-        float csum = 0.f;
 #pragma unroll
-        for (int t = 0; t < NTC; ++t)
-            if (t < nt) {
+        for (int qh = 0; qh < QH; ++qh) {
+            float cm = cmax[qh];
+            cm = fmaxf(cm, __shfl_xor(cm, 16));
+            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            const float m_new = fmaxf(m_run[qh], cm);  // finite: every chunk holds at least one valid key
+            const float alpha = exp2f((m_run[qh] - m_new) * 1.4426950408889634f);  // 0 on the first chunk
+            const float mb = -m_new * 1.4426950408889634f;
+            float csum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = MDR_ATTN_ABL == 5 ? fmaf(s[t][r], 1.4426950408889634f, mb)
-                                                      : __builtin_amdgcn_exp2f(fmaf(s[t][r], 1.4426950408889634f, mb));  // argument <= 0 (up to rounding): raw v_exp_f32
-                    s[t][r] = e;
-                    csum += e;
+            for (int t = 0; t < NTC; ++t)
+                if (t < nt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = MDR_ATTN_ABL == 5 ? fmaf(s[qh][t][r], 1.4426950408889634f, mb)
+                                                          : __builtin_amdgcn_exp2f(fmaf(s[qh][t][r], 1.4426950408889634f, mb));  // argument <= 0 (up to rounding): raw v_exp_f32
+                        s[qh][t][r] = e;
+                        csum += e;
+                    }
                 }
-            }
-        csum += __shfl_xor(csum, 16);
-        csum += __shfl_xor(csum, 32);
-        l_run = l_run * alpha + csum;
-        m_run = m_new;
+            csum += __shfl_xor(csum, 16);
+            csum += __shfl_xor(csum, 32);
+            l_run[qh] = l_run[qh] * alpha + csum;
+            m_run[qh] = m_new;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+            for (int dt = 0; dt < 4; ++dt) o[qh][dt] *= alpha;
+        }
 
         // ---- O^T += V^T P^T. k-slot (g, j) of both operands <-> key 32 pt + (j < 4 ? 4g + j : 16 + 4g + j - 4): the P operand
         // is this lane's own S^T registers, the V^T operand two transposing reads of the row-major V image
 #pragma unroll
         for (int pt = 0; pt < NTC / 2; ++pt)
             if (pt < np) {
-                half8 pf;
+                half8 pf[QH];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    pf[j] = (_Float16)s[2 * pt][j];
-                    pf[4 + j] = (2 * pt + 1 < nt) ? (_Float16)s[2 * pt + 1][j] : (_Float16)0.f;
-                }
+                for (int qh = 0; qh < QH; ++qh)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        pf[qh][j] = (_Float16)s[qh][2 * pt][j];
+                        pf[qh][4 + j] = (2 * pt + 1 < nt) ? (_Float16)s[qh][2 * pt + 1][j] : (_Float16)0.f;
+                    }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    if (MDR_ATTN_ABL == 2 || MDR_ATTN_ABL == 3) { o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[dt & 1], pf, o[dt], 0, 0, 0); continue; }
+                    if (MDR_ATTN_ABL == 2 || MDR_ATTN_ABL == 3) {
+#pragma unroll
+                        for (int qh = 0; qh < QH; ++qh) o[qh][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qh][dt & 1], pf[qh], o[qh][dt], 0, 0, 0);
+                        continue;
+                    }
                     const char* vp = Vs + pt * 4096 + v_rd[dt];
                     const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)vp);
                     const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vp + 2048));
                     const half8 vf = {(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3],
                                       (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+#pragma unroll
+                    for (int qh = 0; qh < QH; ++qh) o[qh][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qh], o[qh][dt], 0, 0, 0);
                 }
             }
     }
-    if (qvalid && MDR_ATTN_ABL != 7) {
+    if (wave_valid && MDR_ATTN_ABL != 7) {
         // The last PV MFMAs sit behind per-pair branches, and hipcc's hazard recogniser does not look across a branch for the
         // distance a VALU read of an MFMA result needs (found with a variant of this kernel that consumed S tiles right behind a
         // per-tile branch: NaNs, gone with the nops). Nothing has ever been wrong here; the 16 wait states are insurance.
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
-        const float inv = 1.f / l_run;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            half4 w;
+        for (int qh = 0; qh < QH; ++qh) {
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(o[qh][0]), "+v"(o[qh][1]), "+v"(o[qh][2]), "+v"(o[qh][3]));
+            const int qi = q0 + qh * 16 + lr;
+            if (qi < len) {
+                const float inv = 1.f / l_run[qh];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w[r] = (_Float16)(o[dt][r] * inv);
-            *(half4*)(ctx + (size_t)(start + qi) * H + h * 64 + dt * 16 + 4 * g) = w;
+                for (int dt = 0; dt < 4; ++dt) {
+                    half4 w;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[r] = (_Float16)(o[qh][dt][r] * inv);
+                    *(half4*)(ctx + (size_t)(start + qi) * H + h * 64 + dt * 16 + 4 * g) = w;
+                }
+            }
         }
     }
     if (sub == 0) MDR_ATTN_STAMP(2);
