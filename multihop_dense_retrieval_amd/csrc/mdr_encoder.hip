@@ -228,8 +228,18 @@ int launch_attention(const _Float16* qkv, const int* cu, int B, int L, int H, in
     return MDR_OK;
 }
 
+int launch_attention_ring(const _Float16* qkv, const int* cu, int B, int L, int H, int heads, _Float16* ctx, hipStream_t st) {
+    { int rc_ = ensure_dynamic_lds((const void*)attention_ring_kernel, kRingLds); if (rc_) return rc_; }
+    const int nblk = (L + 127) / 128;
+    const long long pairs8 = ((long long)B * heads + 7) / 8 * 8;  // pairs rounded up to whole XCD rounds
+    hipLaunchKernelGGL(attention_ring_kernel, dim3((unsigned)(pairs8 * nblk)), dim3(512), kRingLds, st, qkv, cu, B, heads, nblk, H, ctx);
+    MDR_HIP_TRY(hipGetLastError());
+    return MDR_OK;
+}
+
 template <int NTC>
 int launch_attention_stream(const _Float16* qkv, const int* cu, int B, int L, int H, int heads, _Float16* ctx, hipStream_t st) {
+    if (MDR_ATTN_RING) return launch_attention_ring(qkv, cu, B, L, H, heads, ctx, st);  // (the product; MDR_ATTN_RING=0 builds: the streaming kernel)
     constexpr int lds = NTC * 16 * 128 * 2;
     { int rc_ = ensure_dynamic_lds((const void*)attention_stream_kernel<NTC>, lds); if (rc_) return rc_; }
     dim3 grid(heads, B, (L + 127) / 128);

@@ -394,6 +394,236 @@ attention_stream_kernel(const _Float16* __restrict__ qkv, const int* __restrict_
     MDR_ATTN_STAMP(3);
 }
 
+#ifndef MDR_ATTN_RING  // 4: product. Measurement builds: 0 = the streaming kernel above, 1 / 2 = three slots of 64 keys (2: query blocks of a pair on
+#define MDR_ATTN_RING 4  // consecutive workgroup ids), 3 = two slots of 64 keys at 64 VGPRs (four workgroups per CU), 5 = two slots of 128 keys (two per CU)
+#endif
+#ifndef MDR_ATTN_RING_QLDS
+#define MDR_ATTN_RING_QLDS 0
+#endif
+// a wave-uniform value the compiler may not reason about: keeps it from hoisting one 64-bit condition mask per key tile into SGPRs for the whole kernel
+__device__ __forceinline__ int opaque_ring(int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; }
+// ---- attention, ring form (round 4; the kernel the encoder runs for L > 128): one workgroup per (sequence, head, block of 128 queries), built for OCCUPANCY.
+// The streaming kernel's per-workgroup timeline (scripts/gpu_attn_timeline.py, profiles/r04_attention_timeline_product.txt) shows a CU without any workgroup in
+// its compute phase a quarter to a third of the time -- both residents waiting for their K / V together -- and two computing side by side costing each other
+// only 12-30 %: that kernel (124 VGPRs, 64 KiB of LDS: two workgroups per CU) is occupancy-starved, not pipe-bound. Here K and V travel in JOBS of 96 keys
+// through a two-slot LDS ring (a slot: K image [96][64] halfs, then V; 48 KiB in all), the next job's pieces in flight under the current job's arithmetic, and
+// scores live 96 keys at a time (online softmax per job), so the kernel fits 80 VGPRs: THREE workgroups = six waves per SIMD on a CU. Measured on one box, us
+// per layer at the hop-2 shape: streaming kernel 51.7; this 44.8; the same with three slots of 64 keys 47.8-50.6, with two slots of 64 keys at 64 VGPRs (four
+// workgroups per CU) 49.2, with two slots of 128 keys (two per CU) 52.9. What it gives up: the two query blocks of a 129..256-token sequence no longer share one
+// staged K / V image (each block streams the keys itself; the XCD-aware grid keeps the second pass in L2), and its sums differ from the streaming kernel's in
+// rounding for sequences of more than 96 keys (another rescale order; bit-identical up to 96; same parity bars).
+// All LDS fragment reads are inline asm with their own lgkmcnt waits (hipcc puts vmcnt(0) in front of reads it can see while an LDS-DMA is in flight), the
+// barrier is bare (__syncthreads() carries a fence that lowers to vmcnt(0)).
+// MDR_ATTN_RING = 3 (measurement): TWO slots (32 KiB, one job in flight) and 64 VGPRs -- four workgroups per CU. = 4: two slots of 96 keys (48 KiB), three per CU.
+constexpr int kRingSlots = MDR_ATTN_RING >= 3 ? 2 : 3;
+constexpr int kRingJobKeys = MDR_ATTN_RING == 5 ? 128 : MDR_ATTN_RING == 4 ? 96 : 64, kRingSlot = kRingJobKeys * 256, kRingLds = kRingSlots * kRingSlot;
+__global__ void __launch_bounds__(512)
+#if MDR_ATTN_RING == 3
+__attribute__((amdgpu_waves_per_eu(8, 8)))
+#elif MDR_ATTN_RING == 5  // (measurement: two slots of 128 keys = 64 KiB, two workgroups per CU)
+__attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+__attribute__((amdgpu_waves_per_eu(6, 6)))
+#endif
+attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int B, int heads, int nblk, int H, _Float16* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(128))) char lds[];  // (no static LDS: slot 0 starts at LDS address 0)
+    constexpr int HK = kRingJobKeys, SLOT = kRingSlot, TH = HK / 16, NS = kRingSlots, QS = NS - 1;  // QS: the slot the Q rows pass through
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    // 1-D grid, XCD-aware (workgroup id mod 8 = XCD): the query blocks of one (sequence, head) pair run back to back on ONE XCD, so that the second and third
+    // block find the pair's K and V rows in that XCD's L2. pair = 8 * (id / (8 nblk)) + id % 8, block = (id / 8) % nblk.
+#if MDR_ATTN_RING == 2
+    const int pair = blockIdx.x / nblk, blk_z = blockIdx.x - pair * nblk;  // (measurement: blocks of a pair on consecutive ids = different XCDs)
+#else
+    const int pair = 8 * (blockIdx.x / (8 * nblk)) + (blockIdx.x & 7), blk_z = (blockIdx.x >> 3) % nblk;
+#endif
+    if (pair >= B * heads) return;
+    const int b = pair / heads, h = pair - b * heads;
+    const int start = __builtin_amdgcn_readfirstlane(cu[b]), len = __builtin_amdgcn_readfirstlane(cu[b + 1]) - start;
+    const int qb0 = blk_z * 128;
+    if (qb0 >= len) return;
+    const int H3 = 3 * H;
+    const int nh = (len + HK - 1) / HK;
+
+    // DMA plan: wave-instruction i covers LDS slots 64 i .. 64 i + 63 = rows 8 i .. 8 i + 7; this lane: row 8 i + (lane >> 3),
+    // 16-byte slot lane & 7 holding source chunk (lane & 7) ^ (row & 7) = (lane & 7) ^ (lane >> 3)
+    const int st_row = lane >> 3;
+    const int st_col = ((lane & 7) ^ st_row) * 8;
+    // fragment readers (LDS byte addresses inside ring slot 0; images 128-byte aligned): K / Q row lr of a 16-row tile, 16-byte slot (4 ds + g) ^ (lr & 7)
+    // (ds = 1: bit 6 flipped); V: this lane's 8-byte piece for d-tile 0 of pair-tile 0 (d-tile dt: ^ 32 dt)
+    const unsigned k_lds0 = lr * 128 + ((g ^ (lr & 7)) << 4);
+    const int vkey = 4 * g + (lr >> 2);
+    const unsigned v_lds0 = HK * 128 + vkey * 128 + (((((lr & 3) >> 1)) ^ (vkey & 7)) << 4) + (lr & 1) * 8;
+
+    auto pieces_of = [&](int job) __attribute__((always_inline)) { return ((min(HK, len - job * HK) + 31) >> 5) * 4; };  // wave-instructions per image (4 per pair-tile)
+    auto stage = [&](int job, int slot) __attribute__((always_inline)) {  // whole pair-tiles of 32 keys, rows past the sequence clamped to its last row
+        const int pieces = pieces_of(job);
+#pragma unroll
+        for (int k = 0; k < (HK / 8 + 7) / 8; ++k) {  // (64-key jobs: at most one K and one V piece per wave)
+            const int i = wave + 8 * k;
+            if (i < pieces) {
+                int row = job * HK + i * 8 + st_row;
+                row = row < len ? row : len - 1;
+                const _Float16* base = qkv + (size_t)start * H3 + H + h * 64;  // wave-uniform: scalar base + a 32-bit lane offset
+                const unsigned off = (unsigned)(row * H3 + st_col);
+                char* img = lds + slot * SLOT + i * 1024;
+                __builtin_amdgcn_global_load_lds(MDR_GPTR(base + off), MDR_LPTR(img), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(MDR_GPTR(base + H + off), MDR_LPTR(img + HK * 128), 16, 0, 0);
+            }
+        }
+    };
+    auto barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // ---- prologue: this wave's Q fragments (plain register loads) and job 0 (three slots: and job 1) travel together; one wait, and a compiler-visible
+    // use of the Q registers right behind it -- hipcc retires a register load in front of its first use with vmcnt(0), which must not fall behind the next
+    // job's DMA (MDR_ATTN_RING_QLDS=1 builds: Q through the ring's last slot instead, two more barriers)
+    half8 qf[2];
+#if MDR_ATTN_RING_QLDS
+    {
+        const _Float16* qbase = qkv + (size_t)start * H3 + h * 64;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int row = qb0 + (wave * 2 + k) * 8 + st_row;
+            row = row < len ? row : len - 1;
+            __builtin_amdgcn_global_load_lds(MDR_GPTR(qbase + (unsigned)(row * H3 + st_col)), MDR_LPTR(lds + QS * SLOT + (wave * 2 + k) * 1024), 16, 0, 0);
+        }
+    }
+    stage(0, 0);
+    if (NS == 3 && nh > 1) stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier();
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(qf[0]), "=&v"(qf[1]) : "v"(QS * SLOT + wave * 2048 + k_lds0), "v"((QS * SLOT + wave * 2048 + k_lds0) ^ 64u) : "memory");
+    barrier();  // every wave holds its Q fragments: the slot may be refilled
+#else
+    {
+        const int qrow = min(qb0 + wave * 16 + lr, len - 1);
+        const _Float16* qsrc = qkv + (size_t)start * H3 + h * 64 + (unsigned)(qrow * H3 + g * 8);
+        qf[0] = *(const half8*)qsrc;
+        qf[1] = *(const half8*)(qsrc + 32);
+    }
+    stage(0, 0);
+    if (NS == 3 && nh > 1) stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]) : : "memory");
+    barrier();
+#endif
+
+    const int q0 = qb0 + wave * 16;
+    const bool wave_valid = q0 < len;  // waves past the sequence only help staging
+    const int qi = q0 + lr;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int slot = 0;
+    for (int job = 0; job < nh; ++job) {
+        if (job > 0) {
+            // this wave's pieces of job `job` have landed; (three slots) those of job + 1, issued one job ago, may still be out
+            if (NS == 3 && job + 1 < nh && wave < pieces_of(job + 1)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            barrier();  // everyone's pieces of this job are in LDS; everyone is done with job - 1 (its slot takes the next job to be issued)
+        }
+        if (job + NS - 1 < nh) stage(job + NS - 1, slot == 0 ? NS - 1 : slot - 1);
+        if (wave_valid) {
+            const unsigned kb = k_lds0 + slot * SLOT, vb = v_lds0 + slot * SLOT;
+            const int kc0 = job * HK;
+            const int np = opaque_ring(pieces_of(job) >> 2);  // pair-tiles of this job
+            const bool ragged = kc0 + np * 32 > len;         // its last pair-tile holds keys past the sequence (clamped copies of the last row)
+            // ---- S^T tiles: lane holds keys kc0 + 16 t + 4 g + r for query lr
+            f32x4 s[TH];
+            float cmax = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < TH; ++t) {
+                s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                if ((t >> 1) < opaque_ring(np)) {
+                    half8 k0, k1;
+                    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(k0), "=&v"(k1) : "v"(kb), "v"(kb ^ 64u), "n"(t * 2048));
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], acc, 0, 0, 0);
+                    acc *= 0.125f;
+                    if (ragged && (t >> 1) == opaque_ring(np) - 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kc0 + t * 16 + 4 * g + r >= len) acc[r] = -INFINITY;
+                    }
+                    s[t] = acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, acc[r]);
+                }
+            }
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            const float m_new = fmaxf(m_run, cmax);  // finite: every job holds at least one valid key
+            const float alpha = exp2f((m_run - m_new) * 1.4426950408889634f);  // 0 on the first job
+            const float mb = -m_new * 1.4426950408889634f;
+            float csum = 0.f;
+#pragma unroll
+            for (int t = 0; t < TH; ++t)
+                if ((t >> 1) < opaque_ring(np)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], 1.4426950408889634f, mb));  // argument <= 0 (up to rounding): raw v_exp_f32; -inf -> 0
+                        s[t][r] = e;
+                        csum += e;
+                    }
+                }
+            csum += __shfl_xor(csum, 16);
+            csum += __shfl_xor(csum, 32);
+            l_run = l_run * alpha + csum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+            // ---- O^T += V^T P^T. k-slot (g, j) of both operands <-> key 32 pt + (j < 4 ? 4g + j : 16 + 4g + j - 4)
+#pragma unroll
+            for (int pt = 0; pt < TH / 2; ++pt)
+                if (pt < opaque_ring(np)) {
+                    half8 pf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        pf[j] = (_Float16)s[2 * pt][j];
+                        pf[4 + j] = (_Float16)s[2 * pt + 1][j];
+                    }
+#pragma unroll
+                    for (int dp = 0; dp < 2; ++dp) {  // two d-tiles at a time: 8 registers of V fragments in flight
+                        fp16x4_t lo[2], hi[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const unsigned va = vb ^ ((dp * 2 + q) * 32);
+                            asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                                         : "=&v"(lo[q]), "=&v"(hi[q]) : "v"(va), "n"(pt * 4096), "n"(pt * 4096 + 2048));
+                        }
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            if (q == 0) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lo[0]), "+v"(hi[0]));
+                            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[1]), "+v"(hi[1]));
+                            const half8 vf = {(_Float16)lo[q][0], (_Float16)lo[q][1], (_Float16)lo[q][2], (_Float16)lo[q][3],
+                                              (_Float16)hi[q][0], (_Float16)hi[q][1], (_Float16)hi[q][2], (_Float16)hi[q][3]};
+                            o[dp * 2 + q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dp * 2 + q], 0, 0, 0);
+                        }
+                    }
+                }
+        }
+        slot = slot == NS - 1 ? 0 : slot + 1;
+    }
+    if (wave_valid) {
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));  // (see attention_stream_kernel's epilogue)
+        if (qi < len) {
+            const float inv = 1.f / l_run;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                half4 w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = (_Float16)(o[dt][r] * inv);
+                *(half4*)(ctx + (size_t)(start + qi) * H + h * 64 + dt * 16 + 4 * g) = w;
+            }
+        }
+    }
+}
+
 // Last layer: only the CLS row of each sequence feeds the projection head, so its attention needs ONE query per
 // (sequence, head). One wave per (sequence, head): scores over the keys (lane = key), softmax, then lane = feature.
 __global__ void __launch_bounds__(64) attention_cls_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int H,
