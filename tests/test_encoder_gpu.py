@@ -211,12 +211,13 @@ def test_large_batch_kernels_agree_with_small_batch_path(models):
 
 
 def test_attention_query_block_boundaries(models):
-    """Sequence lengths around the attention kernel's block structure -- 128 / 129 (one vs two query blocks), 200, 256 (two blocks served
-    by ONE workgroup that stages K/V once), 257, 300 (two key chunks, three blocks) -- against the numpy restatement of the reference
-    forward (oracle/roberta_oracle.py, fp64) on the 2-layer geometry."""
+    """Sequence lengths around the attention kernel's block structure -- query blocks of 128 (128 / 129 / 130: one vs two blocks; 256 / 257: two vs
+    three), key jobs of 96 through the LDS ring (95 / 96 / 97: one vs two jobs, a ragged last pair-tile; 160 / 161: a job of exactly two pair-tiles vs one
+    more key; 192 / 193, 288 / 289: two vs three and three vs four jobs) -- against the numpy restatement of the reference forward
+    (oracle/roberta_oracle.py, fp64) on the 2-layer geometry."""
     m, sd = models["tiny"]
     geom = seeded.TINY
-    lens = [128, 129, 130, 200, 255, 256, 257, 300, 16, 2]
+    lens = [128, 129, 130, 200, 255, 256, 257, 300, 16, 2, 95, 96, 97, 160, 161, 192, 193, 288, 289, 33]
     L = 300
     rng = np.random.RandomState(5)
     ids = np.full((len(lens), L), 1, np.int64)
