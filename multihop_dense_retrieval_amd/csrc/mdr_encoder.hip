@@ -68,7 +68,7 @@ struct mdr_encoder {
 namespace {
 
 struct Workspace {
-    int *lens, *cu, *total, *tok_src, *tok_pid;
+    int *lens, *cu, *total, *tok_src, *tok_pid, *order;  // order: sequences by length, longest first (the ring attention kernel's walk)
     _Float16 *h16, *qkv, *ctx, *ffn, *cls16;
     float *pre, *clspre, *h32, *cls32;  // h32 / cls32: the fp32 residual stream (residual_fp32 mode only)
     size_t bytes;
@@ -82,6 +82,7 @@ Workspace carve(const mdr_encoder_config& c, int B, int L, char* base) {
     w.lens = (int*)take((size_t)B * 4);
     w.cu = (int*)take((size_t)(B + 1) * 4);
     w.total = (int*)take(4);
+    w.order = (int*)take((size_t)B * 4);
     w.tok_src = (int*)take(T * 4);
     w.tok_pid = (int*)take(T * 4);
     w.h16 = (_Float16*)take(T * c.hidden * 2);
@@ -228,18 +229,18 @@ int launch_attention(const _Float16* qkv, const int* cu, int B, int L, int H, in
     return MDR_OK;
 }
 
-int launch_attention_ring(const _Float16* qkv, const int* cu, int B, int L, int H, int heads, _Float16* ctx, hipStream_t st) {
+int launch_attention_ring(const _Float16* qkv, const int* cu, const int* order, int B, int L, int H, int heads, _Float16* ctx, hipStream_t st) {
     { int rc_ = ensure_dynamic_lds((const void*)attention_ring_kernel, kRingLds); if (rc_) return rc_; }
     const int nblk = (L + 127) / 128;
     const long long pairs8 = ((long long)B * heads + 7) / 8 * 8;  // pairs rounded up to whole XCD rounds
-    hipLaunchKernelGGL(attention_ring_kernel, dim3((unsigned)(pairs8 * nblk)), dim3(512), kRingLds, st, qkv, cu, B, heads, nblk, H, ctx);
+    hipLaunchKernelGGL(attention_ring_kernel, dim3((unsigned)(pairs8 * nblk)), dim3(512), kRingLds, st, qkv, cu, order, B, heads, nblk, H, ctx);
     MDR_HIP_TRY(hipGetLastError());
     return MDR_OK;
 }
 
 template <int NTC>
-int launch_attention_stream(const _Float16* qkv, const int* cu, int B, int L, int H, int heads, _Float16* ctx, hipStream_t st) {
-    if (MDR_ATTN_RING) return launch_attention_ring(qkv, cu, B, L, H, heads, ctx, st);  // (the product; MDR_ATTN_RING=0 builds: the streaming kernel)
+int launch_attention_stream(const _Float16* qkv, const int* cu, const int* order, int B, int L, int H, int heads, _Float16* ctx, hipStream_t st) {
+    if (MDR_ATTN_RING) return launch_attention_ring(qkv, cu, order, B, L, H, heads, ctx, st);  // (the product; MDR_ATTN_RING=0 builds: the streaming kernel)
     constexpr int lds = NTC * 16 * 128 * 2;
     { int rc_ = ensure_dynamic_lds((const void*)attention_stream_kernel<NTC>, lds); if (rc_) return rc_; }
     dim3 grid(heads, B, (L + 127) / 128);
@@ -455,7 +456,8 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
     const long long* mask = (const long long*)mask_dev;
 
     hipLaunchKernelGGL(enc_lens_kernel, dim3((B + 3) / 4), dim3(256), 0, st, mask, B, L, w.lens);
-    hipLaunchKernelGGL(enc_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)w.lens, B, w.cu, w.total);
+    const int* order = (MDR_ATTN_SORT && B <= 1024) ? w.order : nullptr;
+    hipLaunchKernelGGL(enc_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)w.lens, B, w.cu, w.total, (int*)order);
     hipLaunchKernelGGL(enc_scatter_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, mask, B, L, c.pad_id, (const int*)w.cu, w.tok_src, w.tok_pid);
     // Residual stream. residual_fp32 = 0: LayerNorm outputs live as fp16 only (GEMM operand AND residual). residual_fp32 = 1:
     // the apex-O1 regime of the reference -- LayerNorm outputs stay fp32 (w.h32) for the residual adds, and only the copy
@@ -508,8 +510,8 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
         }
         constexpr int attn_sel = MDR_ATTN_FORCE;  // compile-time (measurement builds): 1 = one-shot kernel, 2 = streaming kernel, 0 (product) = by length
         if (attn_sel == 2 || (attn_sel == 0 && L > 128)) {
-            rc = L <= 64 ? launch_attention_stream<4>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st)
-                         : launch_attention_stream<16>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
+            rc = L <= 64 ? launch_attention_stream<4>(w.qkv, w.cu, order, B, L, H, c.heads, w.ctx, st)
+                         : launch_attention_stream<16>(w.qkv, w.cu, order, B, L, H, c.heads, w.ctx, st);
         } else if (L <= 128) rc = launch_attention<8>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         else if (L <= 384) rc = launch_attention<24>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);
         else rc = launch_attention<32>(w.qkv, w.cu, B, L, H, c.heads, w.ctx, st);

@@ -397,18 +397,21 @@ attention_stream_kernel(const _Float16* __restrict__ qkv, const int* __restrict_
 #ifndef MDR_ATTN_RING  // 4: product. Measurement builds: 0 = the streaming kernel above, 1 / 2 = three slots of 64 keys (2: query blocks of a pair on
 #define MDR_ATTN_RING 4  // consecutive workgroup ids), 3 = two slots of 64 keys at 64 VGPRs (four workgroups per CU), 5 = two slots of 128 keys (two per CU)
 #endif
+#ifndef MDR_ATTN_SORT  // 1: product -- the ring kernel walks the sequences longest first. 0 (measurement): in batch order
+#define MDR_ATTN_SORT 1
+#endif
 #ifndef MDR_ATTN_RING_QLDS
 #define MDR_ATTN_RING_QLDS 0
 #endif
 // a wave-uniform value the compiler may not reason about: keeps it from hoisting one 64-bit condition mask per key tile into SGPRs for the whole kernel
 __device__ __forceinline__ int opaque_ring(int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; }
 // ---- attention, ring form (round 4; the kernel the encoder runs for L > 128): one workgroup per (sequence, head, block of 128 queries), built for OCCUPANCY.
-// The streaming kernel's per-workgroup timeline (scripts/gpu_attn_timeline.py, profiles/r04_attention_timeline_product.txt) shows a CU without any workgroup in
+// The streaming kernel's per-workgroup timeline (scripts/gpu_attn_timeline.py, profiles/r04_attention_timeline_streaming_kernel.txt) shows a CU without any workgroup in
 // its compute phase a quarter to a third of the time -- both residents waiting for their K / V together -- and two computing side by side costing each other
 // only 12-30 %: that kernel (124 VGPRs, 64 KiB of LDS: two workgroups per CU) is occupancy-starved, not pipe-bound. Here K and V travel in JOBS of 96 keys
 // through a two-slot LDS ring (a slot: K image [96][64] halfs, then V; 48 KiB in all), the next job's pieces in flight under the current job's arithmetic, and
 // scores live 96 keys at a time (online softmax per job), so the kernel fits 80 VGPRs: THREE workgroups = six waves per SIMD on a CU. Measured on one box, us
-// per layer at the hop-2 shape: streaming kernel 51.7; this 44.8; the same with three slots of 64 keys 47.8-50.6, with two slots of 64 keys at 64 VGPRs (four
+// per layer at the hop-2 shape: streaming kernel 51.7; this 44.8 (42.9 with the pairs walked longest sequence first, `order`); the same with three slots of 64 keys 47.8-50.6, with two slots of 64 keys at 64 VGPRs (four
 // workgroups per CU) 49.2, with two slots of 128 keys (two per CU) 52.9. What it gives up: the two query blocks of a 129..256-token sequence no longer share one
 // staged K / V image (each block streams the keys itself; the XCD-aware grid keeps the second pass in L2), and its sums differ from the streaming kernel's in
 // rounding for sequences of more than 96 keys (another rescale order; bit-identical up to 96; same parity bars).
@@ -425,7 +428,8 @@ __attribute__((amdgpu_waves_per_eu(4, 4)))
 #else
 __attribute__((amdgpu_waves_per_eu(6, 6)))
 #endif
-attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, int B, int heads, int nblk, int H, _Float16* __restrict__ ctx) {
+attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ cu, const int* __restrict__ order, int B, int heads, int nblk, int H,
+                      _Float16* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(128))) char lds[];  // (no static LDS: slot 0 starts at LDS address 0)
     constexpr int HK = kRingJobKeys, SLOT = kRingSlot, TH = HK / 16, NS = kRingSlots, QS = NS - 1;  // QS: the slot the Q rows pass through
     const int tid = threadIdx.x, lane = tid & 63;
@@ -439,12 +443,32 @@ attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ 
     const int pair = 8 * (blockIdx.x / (8 * nblk)) + (blockIdx.x & 7), blk_z = (blockIdx.x >> 3) % nblk;
 #endif
     if (pair >= B * heads) return;
-    const int b = pair / heads, h = pair - b * heads;
+    const int bo = pair / heads, h = pair - bo * heads;
+    const int b = order ? __builtin_amdgcn_readfirstlane(order[bo]) : bo;  // (enc_scan_kernel: sequences by length, longest first)
+#if MDR_ATTN_ABL == 9  // timeline build: [0] entry, [1] Q and job 0 landed, [2] first job computed, [3] exit, [4] len, [5] HW_ID, [6] XCC_ID, [7] ticks waited at later job tops
+    const int wg_lin = blockIdx.x;
+    long long t_wait = 0;
+    if (tid == 0 && wg_lin < kAttnStampWgs) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_attn_stamp[wg_lin * 8 + i] = 0;
+    }
+    MDR_ATTN_STAMP(0);
+#endif
     const int start = __builtin_amdgcn_readfirstlane(cu[b]), len = __builtin_amdgcn_readfirstlane(cu[b + 1]) - start;
     const int qb0 = blk_z * 128;
     if (qb0 >= len) return;
     const int H3 = 3 * H;
     const int nh = (len + HK - 1) / HK;
+#if MDR_ATTN_ABL == 9
+    if (tid == 0 && wg_lin < kAttnStampWgs) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_attn_stamp[wg_lin * 8 + 4] = (unsigned long long)len;
+        g_attn_stamp[wg_lin * 8 + 5] = hw;
+        g_attn_stamp[wg_lin * 8 + 6] = xcc;
+    }
+#endif
 
     // DMA plan: wave-instruction i covers LDS slots 64 i .. 64 i + 63 = rows 8 i .. 8 i + 7; this lane: row 8 i + (lane >> 3),
     // 16-byte slot lane & 7 holding source chunk (lane & 7) ^ (row & 7) = (lane & 7) ^ (lane >> 3)
@@ -508,6 +532,7 @@ attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ 
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]) : : "memory");
     barrier();
 #endif
+    MDR_ATTN_STAMP(1);
 
     const int q0 = qb0 + wave * 16;
     const bool wave_valid = q0 < len;  // waves past the sequence only help staging
@@ -520,10 +545,17 @@ attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ 
     int slot = 0;
     for (int job = 0; job < nh; ++job) {
         if (job > 0) {
+#if MDR_ATTN_ABL == 9
+            if (job == 1) MDR_ATTN_STAMP(2);
+            const long long t_top = wall_clock64();
+#endif
             // this wave's pieces of job `job` have landed; (three slots) those of job + 1, issued one job ago, may still be out
             if (NS == 3 && job + 1 < nh && wave < pieces_of(job + 1)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             barrier();  // everyone's pieces of this job are in LDS; everyone is done with job - 1 (its slot takes the next job to be issued)
+#if MDR_ATTN_ABL == 9
+            t_wait += wall_clock64() - t_top;
+#endif
         }
         if (job + NS - 1 < nh) stage(job + NS - 1, slot == 0 ? NS - 1 : slot - 1);
         if (wave_valid) {
@@ -622,6 +654,11 @@ attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ 
             }
         }
     }
+#if MDR_ATTN_ABL == 9
+    if (nh == 1) MDR_ATTN_STAMP(2);
+    MDR_ATTN_STAMP(3);
+    if (tid == 0 && wg_lin < kAttnStampWgs) g_attn_stamp[wg_lin * 8 + 7] = (unsigned long long)t_wait;
+#endif
 }
 
 // Last layer: only the CLS row of each sequence feeds the projection head, so its attention needs ONE query per

@@ -28,10 +28,13 @@ __global__ void __launch_bounds__(256) enc_lens_kernel(const long long* __restri
     if (lane == 0) lens[b] = n;
 }
 
-// single block: exclusive scan of lens -> cu[0..B], total
-__global__ void __launch_bounds__(1024) enc_scan_kernel(const int* __restrict__ lens, int B, int* __restrict__ cu, int* __restrict__ total) {
+// single block: exclusive scan of lens -> cu[0..B], total; and (order != nullptr, B <= 1024) the sequences sorted by length, longest first (ties: lower
+// index first) -> order[0..B): the attention kernel for L > 128 walks its (sequence, head) pairs in that order, so that the workgroups that start last are
+// the short ones (its timeline showed a quarter of the kernel's span draining 12-us workgroups of long sequences that were dispatched last).
+__global__ void __launch_bounds__(1024) enc_scan_kernel(const int* __restrict__ lens, int B, int* __restrict__ cu, int* __restrict__ total, int* __restrict__ order) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
+    __shared__ unsigned skey[1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
@@ -54,6 +57,23 @@ __global__ void __launch_bounds__(1024) enc_scan_kernel(const int* __restrict__ 
         __syncthreads();
     }
     if (tid == 0) { cu[B] = carry_s; *total = carry_s; }
+    if (order == nullptr || B > 1024) return;
+    // bitonic sort, descending, of (len << 10 | 1023 - index) over the next power of two (padding keys 0 sink to the end)
+    int n2 = 1;
+    while (n2 < B) n2 <<= 1;
+    skey[tid] = tid < B ? ((unsigned)lens[tid] << 10) | (unsigned)(1023 - tid) : 0u;
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int p = tid ^ j;
+            if (tid < n2 && p > tid) {
+                const unsigned a = skey[tid], b = skey[p];
+                const bool desc = (tid & k) == 0;  // this stretch is sorted descending
+                if (desc ? a < b : a > b) { skey[tid] = b; skey[p] = a; }
+            }
+            __syncthreads();
+        }
+    if (tid < B) order[tid] = 1023 - (int)(skey[tid] & 1023u);
 }
 
 // one wave per row: packed token t = cu[b] + j  ->  source element b*L+p and RoBERTa position id

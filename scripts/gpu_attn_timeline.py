@@ -1,4 +1,4 @@
-"""Per-workgroup timeline of attention_stream_kernel (a -DMDR_ATTN_ABL=9 build selected with MDR_LIB_PATH): when does each workgroup wait for its
+"""Per-workgroup timeline of the attention kernel for L > 128 (a -DMDR_ATTN_ABL=9 build selected with MDR_LIB_PATH: the ring kernel; with -DMDR_ATTN_RING=0 the streaming kernel): when does each workgroup wait for its
 K/V, when does it compute, and what runs beside it on the same CU? Hop-2-shaped forward as scripts/gpu_enc_forward.py; the stamps are those of the
 LAST streaming-attention launch of the forward (layer 11).
 
@@ -46,6 +46,9 @@ print(f"workgroups launched {nwg}, with work {int(real.sum())}; kernel span {T[:
 ld, c0, rest, life = T[:, 1] - T[:, 0], T[:, 2] - T[:, 1], T[:, 3] - T[:, 2], T[:, 3] - T[:, 0]
 for name, v in (("entry -> K/V landed", ld), ("first query block (S, softmax, PV, stores)", c0), ("rest (second block / further chunks)", rest), ("lifetime", life)):
     print(f"  {name:46s} mean {v.mean():6.2f} us  p10 {np.percentile(v, 10):6.2f}  p50 {np.percentile(v, 50):6.2f}  p90 {np.percentile(v, 90):6.2f}")
+if r[:, 7].max() > 0:  # the ring kernel: ticks waited at the tops of jobs 1.. (its first wait is "entry -> K/V landed": Q and job 0)
+    tw = r[:, 7] / 100.0
+    print(f"  waited at later job tops (wait + barrier)        mean {tw.mean():6.2f} us  p50 {np.percentile(tw, 50):6.2f}  p90 {np.percentile(tw, 90):6.2f}   ({tw.sum() / life.sum():.2f} of the lifetimes)")
 # per CU: (xcc, se, cu) from XCC_ID[3:0], HW_ID se_id[15:13], sh_id[12], cu_id[11:8]
 cu_key = (r[:, 6] & 15) * 4096 + ((r[:, 5] >> 8) & 0xFF)
 per_cu = collections.defaultdict(list)
@@ -86,16 +89,16 @@ if len(rows):
             print(f"  merged 180..230 tokens, share of compute beside the other slot's compute in [{lo_:.2f}, {hi_:.2f}): n {int(sel.sum()):4d}  compute {rows[sel, 1].mean():6.2f} us")
 # per CU: share of the kernel span with 0 / 1 / 2 workgroups in their compute phase
 span_all = T[:, 3].max()
-occ = np.zeros(3)
+occ = np.zeros(4)
 for idx in per_cu.values():
     ev = sorted([(T[i, 1], 1) for i in idx] + [(T[i, 3], -1) for i in idx])
     t_prev, n = 0.0, 0
     for t_, d_ in ev:
-        occ[min(n, 2)] += t_ - t_prev
+        occ[min(n, 3)] += t_ - t_prev
         t_prev, n = t_, n + d_
-    occ[min(n, 2)] += span_all - t_prev
+    occ[min(n, 3)] += span_all - t_prev
 occ /= occ.sum()
-print(f"  CU time with 0 / 1 / 2 workgroups computing: {occ[0]:.2f} / {occ[1]:.2f} / {occ[2]:.2f}")
+print(f"  CU time with 0 / 1 / 2 / 3+ workgroups computing: {occ[0]:.2f} / {occ[1]:.2f} / {occ[2]:.2f} / {occ[3]:.2f}")
 # chip level: how many workgroups are waiting for loads / computing in each 2-us bin
 print("  t(us)  waiting  computing  (of 512 slots)")
 for b0 in np.arange(0.0, span_all + 2.0, 2.0)[:-1]:
