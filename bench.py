@@ -480,6 +480,10 @@ def cli_mode(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    if world > 1 and not args.share_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s) visible (--share-gpu --backend gloo rehearses on one)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     N, d, B = args.rows, args.dim, args.batch
@@ -520,6 +524,8 @@ def cli_mode(args):
     base = [assets["raw_data"], assets["indexpath"], assets["corpus_dict"], assets["model_path"], "--batch-size", str(B), "--beam-size", str(args.beam),
             "--topk", str(args.topk), "--shared-encoder", "--model-name", assets["model_name"], "--gpu", "--max-q-len", str(args.max_q_len),
             "--max-q-sp-len", str(args.max_q_sp_len), "--num-workers", str(args.cli_workers)]
+    if world > 1:  # every leg is its own W-rank job: each rank's child process inherits RANK / WORLD_SIZE / MASTER_* and opens the process group itself
+        base += ["--dist-backend", args.backend] + (["--share-gpu"] if args.share_gpu else [])
     outs = {}
     try:
         import subprocess
@@ -551,8 +557,11 @@ def cli_mode(args):
             texts = [open(p).read() for p in outs.values()]
             result["legs_jsonl_identical"] = all(t == texts[0] for t in texts[1:])
     finally:
-        if world > 1:
-            torch.distributed.barrier()
+        if world > 1:  # no process group in THIS process (the legs' children own the rendezvous port): rank 0 waits on marker files before it removes the assets
+            open(os.path.join(out_dir, f"DONE.rank{rank}"), "w").close()
+            deadline = time.time() + 600
+            while rank == 0 and time.time() < deadline and not all(os.path.exists(os.path.join(out_dir, f"DONE.rank{r}")) for r in range(world)):
+                time.sleep(0.2)
         if rank == 0:
             shutil.rmtree(out_dir, ignore_errors=True)
     if rank == 0:
@@ -563,12 +572,42 @@ def cli_mode(args):
             if "device_loop" in result:
                 result["cli_over_device_loop"] = round(best["value"] / result["device_loop"]["value"], 3)
         print(json.dumps(result), flush=True)
-    if world > 1 and torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): re-exec this very command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` so that N ranks exist, one per GPU.
+    Under a launcher (WORLD_SIZE set) nothing happens here, and a WORLD_SIZE that disagrees with --gpus is an error, not a warning: a scaling record
+    whose n_gpus is not what was asked for is void. Fewer than N visible devices is an error too (unless --share-gpu, the one-GPU debugging mode)."""
+    if args.mode == "encode-corpus":
+        return
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks; refusing to print a line whose n_gpus is not --gpus")
+        return
+    if args.gpus <= 1:
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.share_gpu:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) visible (use --share-gpu --backend gloo to rehearse N ranks on one device)")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: self-launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // args.gpus)))
+    os.execvpe(sys.executable, cmd, env)
 
 
 def main():
     args = parse()
+    self_launch(args)
     if args.mode == "encode-corpus":
         return encode_corpus_mode(args)
     if args.mode == "cli":
@@ -576,10 +615,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    if world > 1 and not args.share_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s) visible (--share-gpu --backend gloo rehearses on one)")
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -638,6 +677,7 @@ def main():
                                f"{B}-question batches{' per GPU (global batch ' + str(GB) + ')' if weak else ''}, 2-hop beam={args.beam} topk={args.topk}"
                                f"{' , MIPS-only (no encoder)' if not pipe.use_encoder else ', RoBERTa-base encoder (random init)'}",
                    "rows": N, "dim": d, "batch": B, "global_batch": GB, "beam": args.beam, "topk": args.topk, "shards": world,
+                   "collective_world_size": (dist.get_world_size() if dist is not None else 1), "collective_backend": (dist.get_backend() if dist is not None else None),
                    "encoder": pipe.encoder_desc(), "index_build_s": round(build_s, 2),
                    "loop": ("software-pipelined, two batches deep: hop 2 of batch i beside hop 1 of batch i+2 (two concurrent encoder forwards, two lanes / streams), "
                             "their ONE fused corpus pass on a third stream beside the encoder forwards of step i+1, path ranking behind it (every batch still walks "

@@ -23,10 +23,10 @@ def _need_two():
 
 def _run(n, extra, port):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable]
-    if n > 1:
-        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port)]
-    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--rows", "2000000", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"] + extra
+    # the plain command, no launcher: bench.py --gpus N starts its own N ranks (bench.self_launch); `port` only keeps the old signature
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--rows", "2000000", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
