@@ -6,7 +6,7 @@ import json
 import numpy as np
 import pytest
 
-from oracle import roberta_oracle, seeded
+from oracle import mhop_oracle, roberta_oracle, seeded
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -140,7 +140,7 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys, tiny_roberta_tokenizer):
     got_hop1 = {c[0]["title"] for c in rec["candidate_chains"]}
     assert got_hop1 <= {f"T{i}" for i in best3} | {f"T{i}" for i in np.argsort(-scores)[:5].tolist()}
     # ... and the WHOLE run against the reference loop recomputed with the oracle (eval_mhop_retrieval.py:142-206 on the saved index: fp64 restatement of the
-    # encoder, exact inner products, the reference's own pair construction and path ranking -- oracle/mhop_oracle.py's expressions via mhop.rank_paths).
+    # encoder, exact inner products, the reference's own pair construction and path ranking -- oracle/mhop_oracle.rank_paths).
     # The HIP encoder's embeddings differ from the fp64 ones by fp16-operand noise, so a chain may differ where two path scores are closer than that noise:
     # every question's best chain must be the oracle's best chain or lose to it by less than the noise, and most questions must agree on all four chains.
     from multihop_dense_retrieval_amd import mhop
@@ -162,7 +162,7 @@ def test_encode_corpus_then_eval_mhop(tmp_path, capsys, tiny_roberta_tokenizer):
             s2 = xb64 @ roberta_oracle.encode(sd, geom, i2, m2, np.float64)[0]
             I2[j] = np.argsort(-s2, kind="stable")[:3]
             D2[j] = s2[I2[j]]
-        want = mhop.rank_paths(D1[None], I1[None], D2.reshape(1, 9), I2.reshape(1, 9), 3, 4)[0]
+        want = mhop_oracle.rank_paths(D1[None], I1[None], D2.reshape(1, 9), I2.reshape(1, 9), 3, 4)[0]  # the restatement, itself held to the reference script's own run (tests/test_cli_reference_fixture.py)
         got = [(c[0]["title"], c[1]["title"]) for c in json.loads(lines[qi])["candidate_chains"]]
         want_t = [(f"T{h1}", f"T{h2}") for h1, h2, _ in want]
         agree_all += got == want_t
