@@ -5,6 +5,8 @@ GPU -> host dict lookup -> Python tokenizer -> GPU between the hops as the refer
 `longest_first` truncation to max_q_sp_len, empty passages replaced by their title with the hop-1 score set to -inf."""
 import ctypes
 
+import os
+
 import numpy as np
 import torch
 
@@ -80,8 +82,11 @@ class TokenArena:
 
     def save(self, path, tag=""):
         """np.savez appends ".npz" unless the name ends with it; `tag` (arena_tag) records what the tokens are valid for."""
-        np.savez(path, tokens=self.tokens.cpu().numpy(), offsets=self.offsets.cpu().numpy(),
+        final = path if path.endswith(".npz") else path + ".npz"
+        tmp = final + f".tmp{os.getpid()}.npz"  # written under another name and renamed: a rank polling for the file never reads a partial one
+        np.savez(tmp, tokens=self.tokens.cpu().numpy(), offsets=self.offsets.cpu().numpy(),
                  empty=(np.zeros(0, np.uint8) if self.empty is None else self.empty.cpu().numpy()), tag=np.array(str(tag)))
+        os.replace(tmp, final)
 
     @classmethod
     def load(cls, path, expect_tag=None):

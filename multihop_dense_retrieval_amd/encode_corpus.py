@@ -254,6 +254,12 @@ def main(argv=None, tokenizer=None):
     path, _ = encode_shard(model, dataset, args, rank, world, cfg.hidden_size, barrier=barrier)
     n = len(dataset)
     if rank == 0:
+        # what the rows are valid for: the encoder's numerics mode (mdr_encoder_config.residual_fp32) and the token caps; the eval CLI warns
+        # when its query encoder runs another mode than the corpus was encoded under (within-noise ranking flips are then possible)
+        import json
+        with open(args.embed_save_path + ".meta.json", "w") as f:
+            json.dump({"rows": n, "dim": int(cfg.hidden_size), "encoder_numerics": {"residual_fp32": int(model.residual_fp32)},
+                       "max_c_len": int(args.max_c_len), "init_checkpoint": os.path.basename(args.init_checkpoint)}, f)
         print(torch.Size((n, cfg.hidden_size)))
     return path
 

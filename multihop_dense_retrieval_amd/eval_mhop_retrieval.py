@@ -65,7 +65,7 @@ def build_parser():
     p.add_argument("--pipeline-batches", action="store_true", help="(default since round 4; kept so that older command lines still parse)")
     p.add_argument("--no-pipeline-batches", action="store_true",
                    help="one corpus pass per hop and batch, hop-1 and hop-2 forwards one after the other (the fused form gives the same bytes of output)")
-    # extension: batches in flight in the host/device software pipeline (pipeline.py; default: 2 with --hop2-on-device, else 4)
+    # extension: batches in flight in the host/device software pipeline (pipeline.py; default: 2 with --hop2-on-device, else 8)
     p.add_argument("--inflight", type=int, default=None)
     # multi-GPU launches (torch.distributed.run): "nccl" is RCCL; gloo (+ --share-gpu: every rank on cuda:0) exists for the tests
     p.add_argument("--dist-backend", default="nccl")
@@ -105,17 +105,75 @@ def load_corpus(corpus_dict, use_store, rank=0, world=1):
 
     if rank == 0 and not fresh():
         logger.info("Building the corpus store once...")
-        build_store(corpus_dict, store)  # (written to a temporary name and renamed: a reader never sees a partial file)
+        with _failure_marker(store):
+            build_store(corpus_dict, store)  # (written to a temporary name and renamed: a reader never sees a partial file)
     if world > 1:  # the other ranks wait for the file, not for a collective: this runs before the process touches the device
-        import time
-        while not fresh():
-            time.sleep(0.2)
+        wait_for_file(fresh, store, "the corpus store")
     return mhop.load_corpus_dict(store)
+
+
+class _failure_marker:
+    """Rank 0 builds a shared file while the other ranks poll for it (wait_for_file): if the build raises, `<file>.failed` tells them to stop waiting."""
+
+    def __init__(self, target):
+        self.marker = target + ".failed"
+
+    def __enter__(self):
+        if os.path.exists(self.marker):
+            os.remove(self.marker)
+
+    def __exit__(self, et, ev, tb):
+        if et is not None:
+            try:
+                with open(self.marker, "w") as f:
+                    f.write(f"{et.__name__}: {ev}\n")
+            except OSError:
+                pass
+        return False
+
+
+def wait_for_file(ready, target, what, timeout=None, poll=0.2, beat=30.0):
+    """Ranks other than 0: poll until `ready()`; a heartbeat line every `beat` seconds, RuntimeError when rank 0 left `<target>.failed` or after
+    `timeout` seconds (MDR_SHARED_FILE_TIMEOUT, default 6 h -- tokenising / indexing a 5 M-passage corpus takes minutes, never hours). A file, not a
+    collective: a pending RCCL collective is aborted by the process-group watchdog after its own timeout (10 min by default)."""
+    import time
+    timeout = float(os.environ.get("MDR_SHARED_FILE_TIMEOUT", 6 * 3600)) if timeout is None else timeout
+    t0 = last = time.monotonic()
+    while not ready():
+        now = time.monotonic()
+        if os.path.exists(target + ".failed"):
+            raise RuntimeError(f"rank 0 failed to build {what} ({target}): {open(target + '.failed').read().strip()}")
+        if now - t0 > timeout:
+            raise RuntimeError(f"gave up waiting for {what} ({target}) after {timeout:.0f} s: is rank 0 alive?")
+        if now - last >= beat:
+            logging.getLogger().warning(f"rank {os.environ.get('RANK', '?')}: still waiting for rank 0 to write {what} ({target}), {now - t0:.0f} s")
+            last = now
+        time.sleep(poll)
 
 
 def bf16_sidecar_path(indexpath):
     """`<name>.bf16.npy` next to `<name>.npy`: the same matrix as uint16 bf16 bit patterns (encode_corpus --save_bf16)."""
     return (indexpath[:-4] if indexpath.endswith(".npy") else indexpath) + ".bf16.npy"
+
+
+def index_meta_path(indexpath):
+    """`<name>.meta.json` next to `<name>.npy` (written by encode_corpus: numerics mode of the encoder that produced the rows)."""
+    return (indexpath[:-4] if indexpath.endswith(".npy") else indexpath) + ".meta.json"
+
+
+def check_index_numerics(indexpath, model):
+    """Warn when the corpus rows were encoded under another residual-stream numerics mode than the query encoder runs (the default moved from mode 0 to
+    the apex-O1-faithful mode 2 in round 4: an index encoded by an older build is searched with slightly different query embeddings). No file, no check."""
+    try:
+        with open(index_meta_path(indexpath)) as f:
+            mode = json.load(f)["encoder_numerics"]["residual_fp32"]
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+    mine = int(getattr(model, "residual_fp32", -1))
+    if int(mode) != mine:
+        logger.warning(f"index {indexpath} was encoded with residual_fp32={mode}, the query encoder runs residual_fp32={mine}: re-encode the corpus or set "
+                       f"MDR_RESIDUAL_FP32={mode} for bit-consistent embeddings")
+    return int(mode)
 
 
 def load_index(indexpath, d=768, storage="f32"):
@@ -252,6 +310,7 @@ def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, be
 
     logger.info("Building index...")
     index = load_index(args.indexpath, d=bert_config.hidden_size, storage=args.index_storage)
+    check_index_numerics(args.indexpath, model)
 
     roberta = "roberta" in args.model_name
     arena = None
@@ -259,20 +318,28 @@ def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, be
         from .arena import TokenArena, arena_tag
         cache = args.corpus_dict + ".arena.npz"
         tag = arena_tag(tokenizer, roberta, args.max_q_sp_len)
-        arena = TokenArena.load(cache, expect_tag=tag) if os.path.exists(cache) else None  # None: written under another tokenisation rule
-        stale = torch.tensor([0 if arena is not None else 1])
-        if world > 1:  # every rank must take the same branch (a rank that sees the fresh file later must not skip the barrier)
-            stale = stale.cuda() if dist.get_backend() == "nccl" else stale
-            dist.all_reduce(stale, op=dist.ReduceOp.MAX)
-        if int(stale.item()):
-            if rank == 0:
-                logger.info("Tokenising the corpus once for device-side hop-2 assembly...")
+        def load_arena():
+            try:
+                return TokenArena.load(cache, expect_tag=tag) if os.path.exists(cache) else None  # None: written under another tokenisation rule
+            except (OSError, ValueError, EOFError):
+                return None
+
+        arena = load_arena()
+        # No collective around the build: rank 0 tokenises when ITS view of the cache is stale and replaces the file atomically; the
+        # other ranks poll for a file with the right tag. (A rank that already holds a valid arena keeps it: same tag = same tokens.)
+        if arena is None and rank == 0:
+            logger.info("Tokenising the corpus once for device-side hop-2 assembly...")
+            with _failure_marker(cache):
                 arena = TokenArena.from_corpus(id2doc, tokenizer, roberta=roberta, max_tokens=args.max_q_sp_len)
                 arena.save(cache, tag=tag)
-            if world > 1:
-                dist.barrier()
-                if rank != 0:
-                    arena = TokenArena.load(cache, expect_tag=tag)
+        elif arena is None:
+            box = {}
+
+            def ready():
+                box["a"] = load_arena()
+                return box["a"] is not None
+            wait_for_file(ready, cache, "the token arena", poll=1.0)
+            arena = box["a"]
         arena = arena.to(torch.device("cuda"))
 
     logger.info("Encoding questions and searching")

@@ -97,6 +97,20 @@ def _finish_task(ann, D, I, D2, I2):
     return _FINISH_FN(ann, D, I, D2, I2)
 
 
+def fork_workers_allowed(workers, what):
+    """Worker processes are forked, and a fork must come BEFORE the process touches the HIP device: a child that inherits a live runtime (and the
+    Pool's handler threads of an earlier call) is the classic fork-with-threads hazard, and every later device allocation of the parent got ~50x slower
+    (measured). The CLI keeps that order on its first call; a SECOND in-process call (tests, notebooks) arrives with the device
+    already initialised: it runs with workers = 0 (same results, inline) and says so, unless MDR_ALLOW_LATE_FORK=1."""
+    workers = max(0, int(workers))
+    if workers > 0 and torch.cuda.is_available() and torch.cuda.is_initialized() and os.environ.get("MDR_ALLOW_LATE_FORK", "0") != "1":
+        import warnings
+        warnings.warn(f"{what}: the HIP runtime is already initialised in this process; not forking {workers} worker process(es) after it -- running "
+                      f"inline (workers = 0). Start a fresh process, or set MDR_ALLOW_LATE_FORK=1.", RuntimeWarning, stacklevel=3)
+        return 0
+    return workers
+
+
 class FinishPool:
     """Path ranking / metrics / output records of a batch are pure Python over id2doc: in the issuing process they fight the launching thread for
     the GIL (measured: 13 ms of finisher time per batch and a 2x slower loop). `workers` forked processes run `finish` instead; they are forked AFTER
@@ -104,6 +118,7 @@ class FinishPool:
 
     def __init__(self, finish, workers):
         self.finish, self.pool = finish, None
+        workers = fork_workers_allowed(workers, "FinishPool")
         if workers > 0:
             self.pool = multiprocessing.get_context("fork").Pool(int(workers), initializer=_finish_init, initargs=(finish,))
 
@@ -127,7 +142,7 @@ class TokenizerPool:
 
     def __init__(self, tokenizer, workers):
         self.tokenizer = tokenizer
-        self.workers = max(0, int(workers))
+        self.workers = fork_workers_allowed(workers, "TokenizerPool")
         self.pool = None
         self._inline_lock = threading.Lock()  # HF fast tokenizers are not re-entrant ("Already borrowed"): inline calls come from several threads
         if self.workers > 0:
@@ -290,6 +305,13 @@ class TwoHopPipeline:
         if n < n_pad:  # a fixed block per rank: the collective's shape must not depend on a ragged last batch
             qp = torch.zeros((n_pad, q.shape[1]), dtype=q.dtype, device=q.device)
             qp[:n] = q
+            # pad rows are searched by every rank and thrown away: an all-zero query would tie EVERY corpus row at score 0, overflow the screen kernels'
+            # candidate lists and send the whole call (the real queries too) through the exact fallback pass. A pad row is a copy of this
+            # rank's last real query, or the first basis vector on a rank without one (scores = column 0 of the corpus: generic, tie-free).
+            if n > 0:
+                qp[n:] = q[n - 1]
+            else:
+                qp[:, 0] = 1.0
         allq = all_gather_dim0(qp.contiguous(), self.world, self.group)
         self.stats["queries_searched"] += int(allq.shape[0])
         D, I = self.index.search_device(allq, self.beam)

@@ -24,7 +24,8 @@ def encode_np(tok, a, b, max_length, pad):
     return np.asarray(ids, np.int64), np.asarray(mask, np.int64)
 
 
-def test_encode_corpus_then_eval_mhop(tmp_path, capsys, tiny_roberta_tokenizer):
+def test_encode_corpus_then_eval_mhop(tmp_path, capsys, tiny_roberta_tokenizer, monkeypatch):
+    monkeypatch.setenv("MDR_ALLOW_LATE_FORK", "1")  # this process has long touched the device: keep the --num-workers 2 run on worker processes
     from multihop_dense_retrieval_amd import encode_corpus, eval_mhop_retrieval
     tok = tiny_roberta_tokenizer  # a real HF byte-level BPE class (tests/golden/tiny_bpe), not a whitespace stand-in
     geom = dict(seeded.TINY, hidden=768, heads=12, ffn=512, vocab=max(seeded.TINY["vocab"], len(tok)))  # index dimension must be 768

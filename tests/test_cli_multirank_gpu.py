@@ -55,8 +55,9 @@ def cli_args(a, out, extra):
 
 
 @pytest.mark.parametrize("extra", [[], ["--hop2-on-device", "--no-pipeline-batches"]], ids=["default", "device+unfused"])
-def test_one_rank_pipeline_variants_agree(toy_assets, extra):
+def test_one_rank_pipeline_variants_agree(toy_assets, extra, monkeypatch):
     """Worker processes / in-flight depth / fusion do not change a byte of the output (one rank)."""
+    monkeypatch.setenv("MDR_ALLOW_LATE_FORK", "1")  # the worker-process run below is the point; this pytest process has long touched the device
     from multihop_dense_retrieval_amd import eval_mhop_retrieval
     a = toy_assets
     base = a["tmp"] / "base.jsonl"

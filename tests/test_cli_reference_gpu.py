@@ -77,7 +77,7 @@ def test_cli_chains_against_the_reference_scripts_run(golden, assets, tmp_path, 
         n_equal = sum(a == b for a, b in zip(lines, ref_lines))
     else:
         n_equal = None
-    worst, top_equal, all_equal = 0.0, 0, 0
+    worst, top_equal, all_equal, pos_equal, overlap = 0.0, 0, 0, 0.0, 0.0
     for n, ln in enumerate(lines):
         rec = json.loads(ln)
         assert list(rec.keys()) == ["_id", "question", "candidate_chains"] and rec["_id"] == f"q{n}" and len(rec["candidate_chains"]) == topk
@@ -85,6 +85,8 @@ def test_cli_chains_against_the_reference_scripts_run(golden, assets, tmp_path, 
         want = case["chain_titles"][n]
         top_equal += got[0] == want[0]
         all_equal += got == want
+        pos_equal += sum(g == w for g, w in zip(got, want)) / topk
+        overlap += len(set(map(tuple, got)) & set(map(tuple, want))) / len(set(map(tuple, want)))
         # every chain the CLI returned must be one of the script's beam x beam paths or lose to the script's k-th best by less than the noise
         by_title = {}
         for (a, c), s in truth[n].items():
@@ -97,10 +99,14 @@ def test_cli_chains_against_the_reference_scripts_run(golden, assets, tmp_path, 
                 continue  # a path outside the script's beams: its hop-1 / hop-2 candidate sets differed at a near-tie; counted by all_equal
             worst = max(worst, kth - s)
     print(f"case {ci} beam {beam} topk {topk}: best chain equal {top_equal}/23, all chains equal {all_equal}/23, JSONL lines byte-equal {n_equal}, "
-          f"worst captured-score deficit of a returned chain {worst:.3e}")
-    # measured (round 5): see profiles/r05_cli_reference_parity.txt
+          f"chain positions equal {pos_equal / 23:.3f}, chain-set overlap {overlap / 23:.3f}, worst captured-score deficit of a returned chain {worst:.3e}")
+    # measured (round 5, profiles/r05_cli_reference_parity.txt): 23 / 22 / 23 of 23 records byte-equal at beam 1 / 3 / 5; at beam 50 x topk 50 (2 500 paths per
+    # question, path scores ~1e2, neighbours ~1e-2 apart) every best chain equal, no question with all 50 chains in the same order
     assert top_equal >= 21 and worst <= 0.25
-    assert all_equal >= (20 if beam <= 5 else 12)
+    if beam <= 5:
+        assert all_equal >= 20
+    else:
+        assert overlap / 23 >= 0.85 and pos_equal / 23 >= 0.3
     # the log lines are the reference's, value for value when every chain agrees
     for needle in case["log"][:6]:
         assert needle in err, needle

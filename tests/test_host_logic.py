@@ -282,3 +282,32 @@ def test_arena_cache_is_rebuilt_when_its_tokenisation_rule_differs(tmp_path, tin
     np.savez(str(tmp_path / "old.npz"), tokens=a.tokens.numpy(), offsets=a.offsets.numpy(), empty=a.empty.numpy())  # a cache of round 3: no tag
     assert TokenArena.load(str(tmp_path / "old.npz"), expect_tag=tag) is None
     assert TokenArena.load(str(tmp_path / "old.npz")) is not None  # (explicit loads without a tag still work)
+
+
+def test_wait_for_file_deadline_heartbeat_and_failure_marker(tmp_path, caplog):
+    """ranks != 0 poll for files rank 0 builds (corpus store, token arena) -- with a deadline, a heartbeat and a failure marker."""
+    from multihop_dense_retrieval_amd import eval_mhop_retrieval as ev
+    target = str(tmp_path / "thing")
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        ev.wait_for_file(lambda: False, target, "the thing", timeout=0.3, poll=0.05, beat=0.1)
+    with pytest.raises(ValueError):
+        with ev._failure_marker(target):
+            raise ValueError("disk full")
+    with pytest.raises(RuntimeError, match="rank 0 failed to build the thing.*disk full"):
+        ev.wait_for_file(lambda: False, target, "the thing", timeout=5, poll=0.05)
+    with ev._failure_marker(target):  # a later successful build clears the marker
+        pass
+    ev.wait_for_file(lambda: True, target, "the thing", timeout=1)
+
+
+def test_index_numerics_mismatch_warns(tmp_path, caplog):
+    import types
+    from multihop_dense_retrieval_amd import eval_mhop_retrieval as ev
+    idx = str(tmp_path / "emb.npy")
+    assert ev.check_index_numerics(idx, types.SimpleNamespace(residual_fp32=2)) is None  # no metadata, no check
+    with open(ev.index_meta_path(idx), "w") as f:
+        json.dump({"encoder_numerics": {"residual_fp32": 0}}, f)
+    import logging
+    with caplog.at_level(logging.WARNING):
+        assert ev.check_index_numerics(idx, types.SimpleNamespace(residual_fp32=2)) == 0
+    assert "residual_fp32=0" in caplog.text and "MDR_RESIDUAL_FP32=0" in caplog.text
