@@ -551,7 +551,7 @@ def cli_mode(args):
                 result[f"cli_{name}"] = {"flags": " ".join(legs[name]) or "(the reference's flags)", "value": round(run["questions"] / run["loop_seconds"], 2),
                                         "unit": "queries/s", "loop_seconds": round(run["loop_seconds"], 4), "ms_per_batch": round(run["loop_seconds"] / max(1, -(-run["questions"] // B)) * 1e3, 4),
                                         "steady_state_queries_per_s": steady, "whole_process_seconds": round(wall, 2), "records": sum(1 for _ in open(save)), "graph_captures": run["graph_captures"],
-                                        "graph_replays": run["graph_replays"], "encoder_forward_calls": run["encoder_forward_calls"],
+                                        "graph_replays": run["graph_replays"], "encoder_forward_calls": run["encoder_forward_calls"], "startup_s": run.get("startup_s"),
                                         "stats": {k: v for k, v in run["stats"].items() if k != "batch_done_t"}}
         if rank == 0 and len(outs) >= 2:
             texts = [open(p).read() for p in outs.values()]

@@ -255,6 +255,7 @@ struct SearchPlan {
     int G8;   // its workgroups: TWO per CU (24.25 KiB super-blocks: three slots are 73 KiB), one's barrier and epilogue under the other's MFMAs.
               // Measured at 5 M rows, planted queries, whole call: 1 per CU 1.013 ms, 1 per CU with 64-row stages 0.995 ms, 2 per CU 0.907 ms.
     size_t off_q8, off_qab, off_ctl8, off_gstar;
+    size_t off_zero, zero_bytes, off_gmax_b;  // the k = 1 screen path's zero block (make_plan)
 };
 
 #ifndef MDR_I8W_SLOTS
@@ -298,18 +299,25 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     p.off_qlo = take(frag && !is_bf16(h) ? nq_pad * h->d * 2 : 0);
     p.off_bound = take(frag ? nq_pad * 4 : 0);
     p.off_qscale = take(frag ? nq_pad * 4 : 0);
-    p.off_best = take((size_t)(nq > 0 ? nq : 1) * 8);
-    p.off_gmax = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
-    // k == 1: one private list per wave; k > 1: the [G][kStreamQ] sample maxima
+    // ---- the k = 1 screen path's zero block: everything its tiers expect cleared, contiguous, ONE memset per search call (round 5: seven memset nodes
+    // between the kernels of a 0.9 ms call were seven ~1.5 us boundaries): best | gmax | gmax_b | gstar | ctl8 | sctl ----
     p.i8 = i8_tier(h, p.path, nq, k);
+    p.off_best = take((size_t)(nq > 0 ? nq : 1) * 8);
+    p.off_zero = p.off_best;
+    p.off_gmax = take(p.path == PATH_SCREEN ? nq_pad * 4 : 0);
+    p.off_gmax_b = take(p.path == PATH_SCREEN && p.i8 ? nq_pad * 4 : 0);  // the fp16 tier's sample maxima when it runs BEHIND the int8 tier (which owns gmax)
+    p.off_gstar = take(p.i8 ? nq_pad * 8 : 0);
+    p.off_ctl8 = take(p.i8 ? 256 : 0);  // [0] a candidate list of the int8 tier overflowed -> the fp16 screen runs
+    // k == 1: one private list per wave; k > 1: the [G][kStreamQ] sample maxima
     {
         const long long per_cu = MDR_I8_SLOTS <= 3 ? 2 : 1;  // workgroups of the int8 kernels per CU (LDS: 3 slots are 73 KiB, 6 are 146 KiB)
         p.G8 = (int)(units < per_cu * h->num_cus ? (units > 0 ? units : 1) : per_cu * h->num_cus);
         p.G8w = (int)((units + 1) / 2 < h->num_cus ? ((units + 1) / 2 > 0 ? (units + 1) / 2 : 1) : h->num_cus);  // the 32-queries-per-wave kernel: one per CU, stages of two super-blocks
     }
     const size_t gl = p.i8 && p.G8 > p.G ? (size_t)p.G8 : (size_t)p.G;  // workgroups that own candidate lists
-    p.off_scand = take(p.path != PATH_SCREEN ? 0 : (k == 1 ? gl * 8 * kWaveCandCap * 8 : (size_t)p.G * sample_stages_for(k) * kWideQ * 4));
     p.off_sctl = take(p.path == PATH_SCREEN ? 256 + gl * 8 * 4 : 0);            // [0] overflow flag, [64..] per-wave counts
+    p.zero_bytes = p.off_sctl + (p.path == PATH_SCREEN ? 256 : 0) - p.off_zero;  // (the per-wave counts behind the head are written before they are read)
+    p.off_scand = take(p.path != PATH_SCREEN ? 0 : (k == 1 ? gl * 8 * kWaveCandCap * 8 : (size_t)p.G * sample_stages_for(k) * kWideQ * 4));
     // the screen-k lists and the lists of its conditional exact pass (which runs after them in stream order) share one region
     size_t lists = p.lists_stream ? (size_t)p.Gx * kStreamQ * kStreamCap : (p.lists_generic ? (size_t)p.Gg * kGenericQ * kGenericCap : 0);
     size_t slots = p.lists_stream ? (size_t)p.Gx * kStreamQ : (p.lists_generic ? (size_t)p.Gg * kGenericQ : 0);
@@ -324,8 +332,6 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     p.off_kth = take(slots * 8);
     p.off_q8 = take(p.i8 ? nq_pad * h->d : 0);
     p.off_qab = take(p.i8 ? nq_pad * 16 : 0);
-    p.off_ctl8 = take(p.i8 ? 256 : 0);  // [0] a candidate list of the int8 tier overflowed -> the fp16 screen runs
-    p.off_gstar = take(p.i8 ? nq_pad * 8 : 0);
     p.total = o + 256;
     return p;
 }
@@ -360,16 +366,14 @@ int run_screen(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, 
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen_kernel<NKB, 1, BF>, (int)lds_bytes);
     if (rc_) return rc_;
     float* bound = (float*)(ws + p.off_bound);
-    unsigned* gmax = (unsigned*)(ws + p.off_gmax);
+    unsigned* gmax = (unsigned*)(ws + (run_if && p.i8 ? p.off_gmax_b : p.off_gmax));  // behind the int8 tier: its own maxima (cleared with the zero block)
     u64* scand = (u64*)(ws + p.off_scand);
     int* sctl = (int*)(ws + p.off_sctl);
     int* wave_cnt = sctl + 64;
     const int ngroups = (nq + kStreamQ - 1) / kStreamQ;
-    const int nq_pad = ngroups * kStreamQ;
     const int n_sb = (int)((h->ntotal + 31) / 32);
     const size_t qgroup_bytes = (size_t)kStreamQ * h->d * 2;
-    MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
-    MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
+    // (gmax and sctl[0..63] are part of the search call's zero block: cleared once by mdr_index_search)
     for (int gi = 0; gi < ngroups; ++gi) {
         const int nqg = nq - gi * kStreamQ < kStreamQ ? nq - gi * kStreamQ : kStreamQ;
         const char* qg = qhi + gi * qgroup_bytes;
@@ -397,14 +401,10 @@ int run_screen8(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
     int* ctl8 = (int*)(ws + p.off_ctl8);
     char* q8 = ws + p.off_q8;
     f32x4* qab = (f32x4*)(ws + p.off_qab);
-    const int nq_pad = kStreamQ;
     const int n_sb = (int)((h->ntotal + 31) / 32);
     u64* gstar = (u64*)(ws + p.off_gstar);
-    MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
-    MDR_HIP_TRY(hipMemsetAsync(gstar, 0, (size_t)nq_pad * 8, st));
-    MDR_HIP_TRY(hipMemsetAsync(ctl8, 0, 256, st));
-    hipLaunchKernelGGL(prep_queries_i8_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)(h->flags + 8), q8, qab,
-                       (const float*)h->centre);
+    // (gmax, gstar and ctl8 are part of the search call's zero block: cleared once by mdr_index_search)
+    // (q8 / qab were written by prep_queries_both_kernel, together with the fp16 fragments: mdr_index_search)
     hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 0, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
                        (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar, (const u64*)best);
     // the sample pass's best-lower-bound rows, re-scored exactly: a first `known` that is up to 2 B tighter than their lower bounds
@@ -428,16 +428,14 @@ int run_screen32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen32_kernel<NKB, 1, BF>, (int)lds_bytes);
     if (rc_) return rc_;
     float* bound = (float*)(ws + p.off_bound);
-    unsigned* gmax = (unsigned*)(ws + p.off_gmax);
+    unsigned* gmax = (unsigned*)(ws + (run_if && p.i8 ? p.off_gmax_b : p.off_gmax));  // behind the int8 tier: its own maxima (cleared with the zero block)
     u64* scand = (u64*)(ws + p.off_scand);
     int* sctl = (int*)(ws + p.off_sctl);
     int* wave_cnt = sctl + 64;
     const int ngroups = (nq + kWideQ - 1) / kWideQ;
-    const int nq_pad = ngroups * kWideQ;
     const int n_sb = (int)((h->ntotal + 31) / 32);
     const size_t qgroup_bytes = (size_t)kWideQ * h->d * 2;
-    MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
-    MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
+    // (gmax and sctl[0..63] are part of the search call's zero block: cleared once by mdr_index_search)
     for (int gi = 0; gi < ngroups; ++gi) {
         const int nqg = nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ;
         const char* qg = qhi + gi * qgroup_bytes;
@@ -469,11 +467,8 @@ int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
     const int nq_pad = ngroups * kWideQ;
     const int n_sb = (int)((h->ntotal + 31) / 32);
     u64* gstar = (u64*)(ws + p.off_gstar);
-    MDR_HIP_TRY(hipMemsetAsync(gmax, 0, (size_t)nq_pad * 4, st));
-    MDR_HIP_TRY(hipMemsetAsync(gstar, 0, (size_t)nq_pad * 8, st));
-    MDR_HIP_TRY(hipMemsetAsync(ctl8, 0, 256, st));
-    hipLaunchKernelGGL(prep_queries_i8_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, (const int*)(h->flags + 8), q8, qab,
-                       (const float*)h->centre);
+    // (gmax, gstar and ctl8 are part of the search call's zero block: cleared once by mdr_index_search)
+    // (q8 / qab were written by prep_queries_both_kernel, together with the fp16 fragments: mdr_index_search)
     for (int gi = 0; gi < ngroups; ++gi) {
         const int nqg = nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ;
         const char* qg = q8 + (size_t)gi * kWideQ * h->d;
@@ -782,14 +777,20 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
         MDR_HIP_TRY(hipMemsetAsync(h->flags + 1, 0, sizeof(int), st));  // "a query of THIS call was non-finite" (telemetry)
         if (bf)
             hipLaunchKernelGGL((prep_queries_kernel<true>), dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, h->flags, c, qhi, qlo, bound, qscale, 1.0f);
-        else
+        else if (p.i8 && k == 1) {
+            const int nq_pad8 = wide_pass(nq) ? nq_pad : kStreamQ;  // what run_screen8w / run_screen8 read: whole groups of 256 / one group of 128 queries
+            const int nb16 = (nq_pad + 3) / 4, nb8 = (nq_pad8 + 3) / 4;
+            hipLaunchKernelGGL(prep_queries_both_kernel, dim3(nb16 + nb8), dim3(256), 0, st, nb16, q_dev, nq, nq_pad, nq_pad8, h->d, h->flags, c, qhi, qlo, bound, qscale,
+                               row_unscale(h), ws + p.off_q8, (f32x4*)(ws + p.off_qab), (const float*)h->centre);
+        } else
             hipLaunchKernelGGL((prep_queries_kernel<false>), dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, h->flags, c, qhi, qlo, bound, qscale,
                                row_unscale(h));
         MDR_HIP_TRY(hipGetLastError());
     }
 
     if (k == 1) {
-        MDR_HIP_TRY(hipMemsetAsync(best, 0, (size_t)nq * 8, st));
+        if (p.path == PATH_SCREEN) MDR_HIP_TRY(hipMemsetAsync(ws + p.off_zero, 0, p.zero_bytes, st));  // best + every tier's control words, one node
+        else MDR_HIP_TRY(hipMemsetAsync(best, 0, (size_t)nq * 8, st));
         const int* run_if = nullptr;
         if (p.path == PATH_SCREEN) {
             if (wide_pass(nq) && p.i8) {  // int8 tier, 256 queries per pass; the fp16 wide screen only behind an overflow

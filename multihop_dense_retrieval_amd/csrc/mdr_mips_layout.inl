@@ -164,11 +164,11 @@ __global__ void __launch_bounds__(256) rescale_planes_kernel(char* __restrict__ 
 //               range (2^-25 each), for which the 1e-4 is a second belt.
 // flags[1] is raised for a non-finite query element (results for that query are unspecified, as with FAISS).
 template <bool BF>
-__global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restrict__ q, int nq, int nq_pad, int d, int* __restrict__ flags, float c,
-                                                           char* __restrict__ qhi, char* __restrict__ qlo, float* __restrict__ bound,
-                                                           float* __restrict__ qscale, float xs /* 2^E of the stored rows: folded into qscale */) {
+__device__ __forceinline__ void prep_queries_body(int bx, const float* __restrict__ q, int nq, int nq_pad, int d, int* __restrict__ flags, float c,
+                                                  char* __restrict__ qhi, char* __restrict__ qlo, float* __restrict__ bound,
+                                                  float* __restrict__ qscale, float xs /* 2^E of the stored rows: folded into qscale */) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = bx * 4 + (threadIdx.x >> 6);
     if (i >= nq_pad) return;
     const int nkb = d >> 5, ngrp = d >> 3;
     float mx = 0.f, ss = 0.f;
@@ -213,6 +213,13 @@ __global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restri
         qscale[i] = sc * xs;
         bound[i] = i < nq ? c * (sqrtf(ss) * inv) * sqrtf(__int_as_float(flags[2])) * 1.0001f + 1e-4f : 0.f;
     }
+}
+
+template <bool BF>
+__global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restrict__ q, int nq, int nq_pad, int d, int* __restrict__ flags, float c,
+                                                           char* __restrict__ qhi, char* __restrict__ qlo, float* __restrict__ bound,
+                                                           float* __restrict__ qscale, float xs) {
+    prep_queries_body<BF>((int)blockIdx.x, q, nq, nq_pad, d, flags, c, qhi, qlo, bound, qscale, xs);
 }
 
 __device__ inline int block_sum_256(int v, int* red) {

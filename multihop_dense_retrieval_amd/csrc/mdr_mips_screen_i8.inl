@@ -196,10 +196,10 @@ __global__ void __launch_bounds__(256) convert_to_i8_kernel(const T* __restrict_
 // qab[i][3] = q.c + slack (c = the plane's centre): what is subtracted from an EXACT score of a row to get a valid lower bound of its
 // centred score q.(x - c). slack = 1e-4 sum|q_i c_i| + 2e-6 |q.c| covers the fp32 summation of q.c (768 terms) and the fp32 rounding of
 // x - c in convert_to_i8_kernel; the 1e-3 inflation of alpha / beta covers the rest as before.
-__global__ void __launch_bounds__(256) prep_queries_i8_kernel(const float* __restrict__ q, int nq, int nq_pad, int d, const int* __restrict__ stats,
-                                                              char* __restrict__ q8, f32x4* __restrict__ qab, const float* __restrict__ centre) {
+__device__ __forceinline__ void prep_queries_i8_body(int bx, const float* __restrict__ q, int nq, int nq_pad, int d, const int* __restrict__ stats,
+                                                     char* __restrict__ q8, f32x4* __restrict__ qab, const float* __restrict__ centre) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = bx * 4 + (threadIdx.x >> 6);
     if (i >= nq_pad) return;
     const int nkb8 = d >> 6;
     const bool on = lane < (d >> 4) && i < nq;
@@ -245,6 +245,16 @@ __global__ void __launch_bounds__(256) prep_queries_i8_kernel(const float* __res
         if (!fin) o = (f32x4){0.f, INFINITY, INFINITY, 0.f};
         qab[i] = o;
     }
+}
+
+// ONE launch for both query preparations of a k = 1 search over an fp32-accurate index with an int8 plane (round 5: one kernel boundary less per call):
+// blocks [0, nb16) = prep_queries_body<false> (fp16 hi / lo fragments, bounds, scales), blocks [nb16, nb16 + nb8) = prep_queries_i8_body.
+__global__ void __launch_bounds__(256) prep_queries_both_kernel(int nb16, const float* __restrict__ q, int nq, int nq_pad16, int nq_pad8, int d, int* __restrict__ flags,
+                                                                float c, char* __restrict__ qhi, char* __restrict__ qlo, float* __restrict__ bound,
+                                                                float* __restrict__ qscale, float xs, char* __restrict__ q8, f32x4* __restrict__ qab,
+                                                                const float* __restrict__ centre) {
+    if ((int)blockIdx.x < nb16) prep_queries_body<false>((int)blockIdx.x, q, nq, nq_pad16, d, flags, c, qhi, qlo, bound, qscale, xs);
+    else prep_queries_i8_body((int)blockIdx.x - nb16, q, nq, nq_pad8, d, (const int*)(flags + 8), q8, qab, centre);
 }
 
 template <int NKB8>

@@ -207,9 +207,30 @@ def load_index(indexpath, d=768, storage="f32"):
 
 
 LAST_RUN = {}  # timing / counters of the last main() call of this process (bench.py --mode cli and the tests read it)
+_MARKS = []    # (stage name, perf_counter) of the current main() call: the start-up breakdown of LAST_RUN["startup_s"]
+
+
+def _mark(name):
+    import time
+    _MARKS.append((name, time.perf_counter()))
+
+
+def _startup_breakdown():
+    """{stage: seconds} between consecutive marks, plus how old the process was when main() started (interpreter start + imports: torch, transformers)."""
+    out = {b[0]: round(b[1] - a[1], 4) for a, b in zip(_MARKS, _MARKS[1:])}
+    try:
+        import time
+        import psutil
+        out["process_before_main"] = round(_MARKS[0][2] - psutil.Process().create_time(), 4) if len(_MARKS[0]) > 2 else None  # interpreter start + imports
+    except Exception:
+        pass
+    return out
 
 
 def main(argv=None, tokenizer=None):
+    import time
+    del _MARKS[:]
+    _MARKS.append(("main", time.perf_counter(), time.time()))
     args = build_parser().parse_args(argv)
     _setup_logging()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -226,6 +247,7 @@ def main(argv=None, tokenizer=None):
         tokenizer = AutoTokenizer.from_pretrained(args.model_name)
     from .pipeline import TokenizerPool
     pool = TokenizerPool(tokenizer, args.num_workers)
+    _mark("tokenizer_and_workers")
     try:
         return _run(args, tokenizer, pool, world, rank)
     finally:
@@ -249,14 +271,17 @@ def _run(args, tokenizer, pool, world, rank):
     # runtime: forked after it, every device allocation of the parent -- workspace, hipGraph instantiation -- took ~50x longer, 6.5 s of captures
     # measured), and only then the process touches the device: process group, weights, index. The log lines are the reference's; "Loading corpus..."
     # now comes before "Building index...".
+    _mark("questions")
     logger.info("Loading trained model...")
     bert_config = _load_config(args.model_name)
     model = RobertaRetriever(bert_config, args)
     model = load_saved(model, args.model_path, exact=False, map_location="cpu")
 
+    _mark("checkpoint_to_host")
     logger.info("Loading corpus...")
     id2doc = load_corpus(args.corpus_dict, args.corpus_store, rank, world)
     logger.info(f"Corpus size {len(id2doc)}")
+    _mark("corpus")
 
     class _Memo(dict):
         """Per-batch view of id2doc: a passage is looked up (corpus store: decoded from the map) once, however many chains name it."""
@@ -284,6 +309,7 @@ def _run(args, tokenizer, pool, world, rank):
         return ms, recs
 
     finish_pool = FinishPool(finish_batch, 0 if args.num_workers <= 0 else max(1, min(4, args.num_workers // 4)))
+    _mark("finish_workers_fork")
     try:
         return _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, bert_config, model, id2doc, finish_batch)
     finally:
@@ -300,6 +326,7 @@ def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, be
         dist.init_process_group(args.dist_backend)
     model.to(torch.device("cuda"))
     model.eval()
+    _mark("device_init_and_weights")
     # The loop repeats two shapes (B x max_q_len, B*beam x max_q_sp_len): their hipGraphs are captured here, as part of loading the model (typical fills:
     # questions ~20 of 70 tokens, pairs ~60 % of 350). Any other shape (the ragged last batch) runs eagerly once: capturing it would cost more than it saves.
     # (the larger shape first: a lane's captures hold pointers into its workspace and are dropped when it grows)
@@ -308,9 +335,12 @@ def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, be
     if not args.no_pipeline_batches:
         model.precapture(args.batch_size, args.max_q_len, 0.3, lane=1)
 
+    _mark("graph_captures")
     logger.info("Building index...")
     index = load_index(args.indexpath, d=bert_config.hidden_size, storage=args.index_storage)
     check_index_numerics(args.indexpath, model)
+    torch.cuda.synchronize()
+    _mark("index_upload")
 
     roberta = "roberta" in args.model_name
     arena = None
@@ -342,6 +372,7 @@ def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, be
             arena = box["a"]
         arena = arena.to(torch.device("cuda"))
 
+    _mark("token_arena")
     logger.info("Encoding questions and searching")
     questions = [mhop.strip_question(it["question"]) for it in ds_items]
 
@@ -362,9 +393,10 @@ def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, be
         pipe.close()
     fence()
     loop_s = time.perf_counter() - t0
+    _mark("batch_loop")
     results = gather_results(mine, world)
     LAST_RUN.clear()
-    LAST_RUN.update(loop_seconds=loop_s, questions=len(questions), world=world, rank=rank, stats=dict(pipe.stats),
+    LAST_RUN.update(startup_s=_startup_breakdown(), loop_seconds=loop_s, questions=len(questions), world=world, rank=rank, stats=dict(pipe.stats),
                     encoder_forward_calls=model.forward_calls, encoder_forward_rows=model.forward_rows,
                     graph_captures=model.graph_captures, graph_replays=model.graph_replays)
     if results is None:  # ranks other than 0: their part went to rank 0

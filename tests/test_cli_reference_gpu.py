@@ -106,7 +106,7 @@ def test_cli_chains_against_the_reference_scripts_run(golden, assets, tmp_path, 
     if beam <= 5:
         assert all_equal >= 20
     else:
-        assert overlap / 23 >= 0.85 and pos_equal / 23 >= 0.3
+        assert overlap / 23 >= 0.95 and pos_equal / 23 >= 0.6  # measured 0.997 / 0.820
     # the log lines are the reference's, value for value when every chain agrees
     for needle in case["log"][:6]:
         assert needle in err, needle
