@@ -25,7 +25,7 @@ Prints ONE JSON line on rank 0 with
   cpu_baseline      the FAISS-equivalent CPU path on a bounded row sample (N = 1 only).
   strong_scaling    (N > 1, default weak scaling) the same job with ONE --batch questions for all ranks.
 
-roofline.traffic is HBM bytes per search call from a separate `rocprofv3 --pmc FETCH_SIZE` pass (scripts/gpu_pmc_screen.sh;
+roofline.traffic is HBM bytes per search call from a separate `rocprofv3 --pmc FETCH_SIZE` pass (scripts/measure/gpu_pmc_screen.sh;
 KB x 1024 x 2, the gfx950 correction of MI355X_MICROARCH.md), which cannot run inside this process: the measured ratio
 traffic / algorithmic bytes of each kernel family (profiles/pmc_traffic.json, written by that script with the hash of
 csrc/mdr_mips* at measurement time) is applied to this run's algorithmic bytes -- `traffic_fresh` is false and
@@ -48,7 +48,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense fp16/bf16 MFMA peak
 CHUNK_ROWS = 250_000
 
 # measured HBM fetch bytes per search call / algorithmic bytes (N_pad * d * 4) per kernel family: profiles/pmc_traffic.json, written by
-# scripts/gpu_pmc_screen.sh (rocprofv3 --pmc FETCH_SIZE passes) together with the hash of csrc/mdr_mips.hip at measurement time.
+# scripts/measure/gpu_pmc_screen.sh (rocprofv3 --pmc FETCH_SIZE passes) together with the hash of csrc/mdr_mips.hip at measurement time.
 MIPS_SRC_GLOB = os.path.join(ROOT, "multihop_dense_retrieval_amd", "csrc", "mdr_mips*")  # mdr_mips.hip + the section files it includes
 
 
@@ -115,6 +115,7 @@ def parse():
                          "cli: queries/s of the drop-in CLI itself (scripts/eval/eval_mhop_retrieval.py main()) on synthetic assets of the headline's size")
     ap.add_argument("--questions", type=int, default=7405, help="--mode cli: questions in the synthetic qas file (HotpotQA dev has 7405)")
     ap.add_argument("--cli-dir", default=None, help="--mode cli: where the synthetic assets go (default: /dev/shm when it has room, else /tmp); removed afterwards")
+    ap.add_argument("--cli-keep", action="store_true", help="--mode cli: keep the synthetic assets (and reuse the ones a previous --cli-keep run left in --cli-dir when rows / questions match)")
     ap.add_argument("--cli-workers", type=int, default=16, help="--mode cli: the CLI's --num-workers (tokenizer worker processes; the flag's default is the reference's 10)")
     ap.add_argument("--cli-legs", default="default,device", help="--mode cli: which flag sets to run: default = the reference's flags, device = --hop2-on-device, unfused = --no-pipeline-batches")
     ap.add_argument("--pool", type=int, default=16,
@@ -302,7 +303,7 @@ def mips_roofline(pipe, local, args, d):
                 fresh = ent.get("csrc_sha16") is not None and ent.get("csrc_sha16") == now
                 src = (f"{ent['source']} (measured FETCH_SIZE x 2 / algorithmic bytes = {ratio}; "
                        + ("kernel source unchanged since that measurement" if fresh else
-                          f"STALE: csrc/mdr_mips* was {ent.get('csrc_sha16')} when measured, is {now} now -- re-run scripts/gpu_pmc_screen.sh") + ")")
+                          f"STALE: csrc/mdr_mips* was {ent.get('csrc_sha16')} when measured, is {now} now -- re-run scripts/measure/gpu_pmc_screen.sh") + ")")
         hbm_bytes = alg_bytes * ratio
     else:
         hbm_bytes, src = float(args.pmc_traffic) * len(calls), "--pmc-traffic"
@@ -511,9 +512,28 @@ def cli_mode(args):
     # (2) the assets
     ready = os.path.join(out_dir, "READY")
     if rank == 0:
-        shutil.rmtree(out_dir, ignore_errors=True)
-        assets = cli_bench_assets.build(out_dir, N, args.questions, device, log=lambda m: print(m, file=sys.stderr, flush=True))
-        json.dump(assets, open(ready, "w"))
+        reuse = None
+        if args.cli_keep and os.path.exists(ready):
+            try:
+                reuse = json.load(open(ready))
+                if reuse.get("rows") != N or reuse.get("questions") != args.questions:
+                    reuse = None
+            except (OSError, ValueError):
+                reuse = None
+        for r in range(world):  # markers of an earlier run
+            try:
+                os.remove(os.path.join(out_dir, f"DONE.rank{r}"))
+            except OSError:
+                pass
+        if reuse is None:
+            if os.path.exists(ready):
+                os.remove(ready)
+            shutil.rmtree(out_dir, ignore_errors=True)
+            assets = cli_bench_assets.build(out_dir, N, args.questions, device, log=lambda m: print(m, file=sys.stderr, flush=True))
+            assets["rows"], assets["questions"] = N, args.questions
+            json.dump(assets, open(ready, "w"))
+        else:
+            assets = reuse
     else:
         while not os.path.exists(ready):
             time.sleep(0.5)
@@ -562,7 +582,7 @@ def cli_mode(args):
             deadline = time.time() + 600
             while rank == 0 and time.time() < deadline and not all(os.path.exists(os.path.join(out_dir, f"DONE.rank{r}")) for r in range(world)):
                 time.sleep(0.2)
-        if rank == 0:
+        if rank == 0 and not args.cli_keep:
             shutil.rmtree(out_dir, ignore_errors=True)
     if rank == 0:
         best = max((v for k, v in result.items() if k.startswith("cli_")), key=lambda v: v["value"], default=None)

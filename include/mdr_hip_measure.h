@@ -18,17 +18,17 @@ extern "C" {
 
 /* -DMDR_GEMM_ABL=5 builds: the s_memtime timeline the persistent 256x256 GEMM accumulates (shader cycles of wave 0 summed over
  * workgroups: [0] wait + barrier A, [1..3] sub-phases 1-3, [4] wait + barrier B, [5] sub-phase 4, [6] epilogue, [7] K-tiles counted);
- * synchronises the device; reset != 0 clears it. Results of that build are correct. (scripts/gpu_gemm_bench.py) */
+ * synchronises the device; reset != 0 clears it. Results of that build are correct. (scripts/measure/gpu_gemm_bench.py) */
 int mdr_test_gemm_stamps(unsigned long long* out8_host, int reset);
 
 /* -DMDR_I8_ABL=9 builds: the same kind of timeline for the 32-queries-per-wave int8 screen kernel ([0] wait + barrier,
- * [1] exchange + DMA issue, [2] MFMA chain, [3] epilogue, [4] bound sharing, [7] stages). (scripts/gpu_i8_quick.py) */
+ * [1] exchange + DMA issue, [2] MFMA chain, [3] epilogue, [4] bound sharing, [7] stages). (scripts/measure/gpu_i8_quick.py) */
 int mdr_test_i8_stamps(unsigned long long* out8_host, int reset);
 
 /* -DMDR_ATTN_ABL=9 builds: per-workgroup timeline of the LAST attention_stream_kernel launch, 8 words per workgroup
  * (linear id (z * B + b) * heads + h): wall_clock64 (100 MHz, chip-wide) at [0] entry, [1] first K/V chunk landed, [2] first query block
  * stored, [3] exit; [4] sequence length (0: the workgroup left at once), [5] HW_ID, [6] XCC_ID. Results of that build are correct.
- * (scripts/gpu_attn_timeline.py) */
+ * (scripts/measure/gpu_attn_timeline.py) */
 int mdr_test_attn_stamps(unsigned long long* out_host, int max_wgs);
 
 #ifdef __cplusplus

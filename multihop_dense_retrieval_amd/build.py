@@ -30,7 +30,7 @@ def _stale():
 
 def build_lib(force=False, verbose=True, defines=(), out=None):
     """defines / out: build a measurement VARIANT of the library next to the product one (e.g. defines=["MDR_MIPS_DMA_AUX=2"],
-    out="libmdrhip_nt.so"); a process selects it with MDR_LIB_PATH (scripts/gpu_ab.sh). The product build takes neither."""
+    out="libmdrhip_nt.so"); a process selects it with MDR_LIB_PATH (scripts/measure/gpu_ab.sh). The product build takes neither."""
     target = LIB if out is None else os.path.join(HERE, out)
     if out is None and not force and not _stale():
         return LIB

@@ -150,9 +150,9 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #ifndef MDR_ATTN_FORCE
 #define MDR_ATTN_FORCE 0
 #endif
-// measurement builds (wrong results; scripts/gpu_attn_ab.sh): 1 no K fragment reads, 2 no V fragment reads, 3 neither, 4 staging only
+// measurement builds (wrong results; scripts/measure/gpu_attn_ab.sh): 1 no K fragment reads, 2 no V fragment reads, 3 neither, 4 staging only
 // (Q loads, K/V DMA, barrier, context stores), 5 no exp, 6 = 4 with K only, 7 = 4 without the stores, 8 = 4 with one row per DMA piece;
-// 9 = correct results + a per-workgroup timeline (g_attn_stamp, scripts/gpu_attn_timeline.py)
+// 9 = correct results + a per-workgroup timeline (g_attn_stamp, scripts/measure/gpu_attn_timeline.py)
 #ifndef MDR_ATTN_ABL
 #define MDR_ATTN_ABL 0
 #endif
@@ -406,7 +406,7 @@ attention_stream_kernel(const _Float16* __restrict__ qkv, const int* __restrict_
 // a wave-uniform value the compiler may not reason about: keeps it from hoisting one 64-bit condition mask per key tile into SGPRs for the whole kernel
 __device__ __forceinline__ int opaque_ring(int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; }
 // ---- attention, ring form (round 4; the kernel the encoder runs for L > 128): one workgroup per (sequence, head, block of 128 queries), built for OCCUPANCY.
-// The streaming kernel's per-workgroup timeline (scripts/gpu_attn_timeline.py, profiles/r04_attention_timeline_streaming_kernel.txt) shows a CU without any workgroup in
+// The streaming kernel's per-workgroup timeline (scripts/measure/gpu_attn_timeline.py, profiles/r04_attention_timeline_streaming_kernel.txt) shows a CU without any workgroup in
 // its compute phase a quarter to a third of the time -- both residents waiting for their K / V together -- and two computing side by side costing each other
 // only 12-30 %: that kernel (124 VGPRs, 64 KiB of LDS: two workgroups per CU) is occupancy-starved, not pipe-bound. Here K and V travel in JOBS of 96 keys
 // through a two-slot LDS ring (a slot: K image [96][64] halfs, then V; 48 KiB in all), the next job's pieces in flight under the current job's arithmetic, and

@@ -555,7 +555,7 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
 //   barrier A (top of step T, after vmcnt(2)): K-tile T landed            barrier B: every wave's reads of slot s retired
 //   DMA pieces (8 per wave and step, 2 per sub-phase): sub-phases 1-3 of step T carry K-tile T+1 (slot s^1, freed at
 //   barrier B of step T-1), sub-phase 4 the first quarter of K-tile T+2 (slot s).
-// Measured (round 1, scripts/gpu_gemm_bench.py): 9-31 % faster than gemm_persist_kernel at 65k rows (qkv 286 vs 350 us,
+// Measured (round 1, scripts/measure/gpu_gemm_bench.py): 9-31 % faster than gemm_persist_kernel at 65k rows (qkv 286 vs 350 us,
 // ffn1 382 vs 499 us); at 20k rows the 256x256 tile count quantises badly over 8 XCDs x 32 workgroups, so launch_gemm
 // compares the two kernels' round counts per call. A ping-pong variant (two wave groups half a phase apart, 8 barrier
 // intervals of 16 MFMAs per K-tile) was slower than both: a barrier interval cost 650-850 cycles against the 256 of
@@ -563,7 +563,7 @@ gemm_persist_kernel(const _Float16* __restrict__ A, int lda, const _Float16* __r
 using GemmB2 = GemmCfg<256, 256, 2, 4, 2>;
 
 // ABL = the COMPILE-TIME macro MDR_GEMM_ABL of a measurement build (`build.py -DMDR_GEMM_ABL=n --out=libmdrhip_abl.so`, selected with
-// MDR_LIB_PATH by scripts/gpu_gemm_bench.py); the product library is built with 0 and holds none of this. Results are wrong for
+// MDR_LIB_PATH by scripts/measure/gpu_gemm_bench.py); the product library is built with 0 and holds none of this. Results are wrong for
 // ABL != 0 except 5: 1 = no DMA after the prologue, 2 = no LDS fragment reads, 3 = no MFMAs, 4 = no epilogue stores -- which of the
 // CU's pipes the K-loop is waiting for. 5 = correct results + an s_memtime timeline of wave 0 of every workgroup summed into
 // g_gemm_stamp (mdr_test_gemm_stamps, include/mdr_hip_measure.h): [0] wait + barrier A, [1] sub-phase 1 (incl. its fragment reads),

@@ -31,8 +31,12 @@
 #include <cstdlib>
 
 #include <cfloat>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "mdr_common.h"
 
@@ -71,6 +75,11 @@ struct mdr_index {
                              // [8], [9] int8 tier: max row scale, max s_r (L1(x8_r)/2 + d/4) (float bits)
     void* stage = nullptr;   // device staging for host-sourced add()
     size_t stage_bytes = 0;
+    // pipelined host upload (upload_host_rows): two pinned staging buffers, a copy stream, "chunk copied" / "chunk converted" events per slot
+    void* pin[2] = {nullptr, nullptr};
+    size_t pin_bytes = 0;
+    hipStream_t copy_st = nullptr;
+    hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     int variant = 0;
     bool compact = false;    // MDR_STORE_F32X2H_COMPACT: no int8 screening plane
     const char* last_kernel = "none";
@@ -629,6 +638,12 @@ int mdr_index_free(mdr_index* h) {
     if (h->centre) (void)hipFree(h->centre);
     if (h->flags) (void)hipFree(h->flags);
     if (h->stage) (void)hipFree(h->stage);
+    for (int i = 0; i < 2; ++i) {
+        if (h->pin[i]) (void)hipHostFree(h->pin[i]);
+        if (h->ev_copy[i]) (void)hipEventDestroy(h->ev_copy[i]);
+        if (h->ev_done[i]) (void)hipEventDestroy(h->ev_done[i]);
+    }
+    if (h->copy_st) (void)hipStreamDestroy(h->copy_st);
     delete h;
     return MDR_OK;
 }
@@ -639,6 +654,117 @@ int mdr_index_reserve(mdr_index* h, int64_t n_rows) {
     DeviceGuard g(h->device);
     return grow(h, n_rows, nullptr);
 }
+
+namespace {
+
+// memcpy with `nt` threads (page-cache / mmap sources fault their pages in here, in parallel)
+void parallel_copy(char* dst, const char* src, size_t bytes, int nt) {
+    if (nt <= 1 || bytes < (8u << 20)) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t part = (bytes / (size_t)nt + 4095) & ~(size_t)4095;
+    for (int t = 1; t < nt; ++t) {
+        const size_t lo = (size_t)t * part;
+        if (lo >= bytes) break;
+        const size_t len = bytes - lo < part ? bytes - lo : part;
+        th.emplace_back([=] { memcpy(dst + lo, src + lo, len); });
+    }
+    memcpy(dst, src, part < bytes ? part : bytes);
+    for (auto& t : th) t.join();
+}
+
+// Host-sourced rows (pageable memory, np.load(mmap_mode="r") included) -> the shard, as a two-slot pipeline (round 5; VERDICT r4 item 8: the 256 MiB
+// copy -> convert -> sync series took ~2 s of a 5.6 s process for a 15.4 GB index):
+//   producer thread   rows -> pinned slot (parallel memcpy) -> hipMemcpyAsync to the slot's device half on the COPY stream -> "copied" event
+//   calling thread    waits for "copied" on `st`, runs add_any (range fit + conversion kernels, as before), records "converted"
+// so chunk c + 1 is read from the host and crosses PCIe while chunk c is converted; a slot is refilled when its "converted" event has completed.
+// Returns an error code (the caller rolls the index back); `n` rows starting at logical row h->ntotal.
+int upload_host_rows(mdr_index* h, const char* rows, long long n, int src_dtype, size_t row_src, hipStream_t st) {
+    const size_t chunk_bytes_target = 96ull << 20;
+    const long long chunk_rows = (long long)(chunk_bytes_target / row_src) > 0 ? (long long)(chunk_bytes_target / row_src) : 1;
+    const size_t chunk_bytes = (size_t)chunk_rows * row_src;
+    const long long nchunks = (n + chunk_rows - 1) / chunk_rows;
+    if (2 * chunk_bytes > h->stage_bytes) {
+        if (h->stage) MDR_HIP_TRY(hipFree(h->stage));
+        h->stage = nullptr;
+        h->stage_bytes = 0;
+        MDR_HIP_TRY(hipMalloc(&h->stage, 2 * chunk_bytes));
+        h->stage_bytes = 2 * chunk_bytes;
+    }
+    if (chunk_bytes > h->pin_bytes) {
+        for (int i = 0; i < 2; ++i) {
+            if (h->pin[i]) MDR_HIP_TRY(hipHostFree(h->pin[i]));
+            h->pin[i] = nullptr;
+        }
+        h->pin_bytes = 0;
+        for (int i = 0; i < 2; ++i) MDR_HIP_TRY(hipHostMalloc(&h->pin[i], chunk_bytes, hipHostMallocDefault));
+        h->pin_bytes = chunk_bytes;
+    }
+    if (!h->copy_st) MDR_HIP_TRY(hipStreamCreateWithFlags(&h->copy_st, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        if (!h->ev_copy[i]) MDR_HIP_TRY(hipEventCreateWithFlags(&h->ev_copy[i], hipEventDisableTiming));
+        if (!h->ev_done[i]) MDR_HIP_TRY(hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
+    }
+    unsigned hc = std::thread::hardware_concurrency();
+    const char* env = getenv("MDR_UPLOAD_THREADS");
+    const int nt = env ? (atoi(env) > 0 ? atoi(env) : 1) : (hc >= 16 ? 8 : hc >= 4 ? (int)hc / 2 : 1);
+
+    std::mutex mu;
+    std::condition_variable cv;
+    long long copied = 0, converted = 0;  // chunks whose H2D copy has been ISSUED / whose conversion has been ISSUED (its event recorded)
+    bool abort_flag = false;
+    int producer_rc = MDR_OK;
+    const int device = h->device;
+    std::thread producer([&] {
+        if (hipSetDevice(device) != hipSuccess) { std::lock_guard<std::mutex> g(mu); producer_rc = MDR_E_HIP; abort_flag = true; cv.notify_all(); return; }
+        for (long long c = 0; c < nchunks; ++c) {
+            const int slot = (int)(c & 1);
+            if (c >= 2) {  // the slot's previous tenant (chunk c - 2) must have been converted: wait until that was issued, then until it completed
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return converted >= c - 1 || abort_flag; });
+                if (abort_flag) return;
+                lk.unlock();
+                if (hipEventSynchronize(h->ev_done[slot]) != hipSuccess) { std::lock_guard<std::mutex> g(mu); producer_rc = MDR_E_HIP; abort_flag = true; cv.notify_all(); return; }
+            }
+            const long long r0 = c * chunk_rows, nr = n - r0 < chunk_rows ? n - r0 : chunk_rows;
+            parallel_copy((char*)h->pin[slot], rows + (size_t)r0 * row_src, (size_t)nr * row_src, nt);
+            bool ok = hipMemcpyAsync((char*)h->stage + (size_t)slot * chunk_bytes, h->pin[slot], (size_t)nr * row_src, hipMemcpyHostToDevice, h->copy_st) == hipSuccess;
+            ok = ok && hipEventRecord(h->ev_copy[slot], h->copy_st) == hipSuccess;
+            std::lock_guard<std::mutex> g(mu);
+            if (!ok) { producer_rc = MDR_E_HIP; abort_flag = true; cv.notify_all(); return; }
+            if (abort_flag) return;
+            copied = c + 1;
+            cv.notify_all();
+        }
+    });
+    int rc = MDR_OK;
+    for (long long c = 0; c < nchunks && rc == MDR_OK; ++c) {
+        const int slot = (int)(c & 1);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return copied > c || abort_flag; });
+            if (abort_flag) { rc = producer_rc ? set_error(producer_rc, "host upload pipeline failed (copy side)") : MDR_E_HIP; break; }
+        }
+        const long long r0 = c * chunk_rows, nr = n - r0 < chunk_rows ? n - r0 : chunk_rows;
+        if (hipStreamWaitEvent(st, h->ev_copy[slot], 0) != hipSuccess) { rc = set_error(MDR_E_HIP, "hipStreamWaitEvent failed in add()"); break; }
+        rc = add_any(h, (char*)h->stage + (size_t)slot * chunk_bytes, src_dtype, nr, h->ntotal + r0, st);
+        if (rc == MDR_OK && hipEventRecord(h->ev_done[slot], st) != hipSuccess) rc = set_error(MDR_E_HIP, "hipEventRecord failed in add()");
+        std::lock_guard<std::mutex> g(mu);
+        if (rc == MDR_OK) converted = c + 1;
+        else abort_flag = true;
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (rc != MDR_OK) abort_flag = true;
+        cv.notify_all();
+    }
+    producer.join();
+    (void)hipStreamSynchronize(h->copy_st);  // nothing of the caller's buffer or the pinned slots is in flight after return
+    if (rc == MDR_OK && hipStreamSynchronize(st) != hipSuccess) rc = set_error(MDR_E_HIP, "stream sync failed in add()");
+    return rc;
+}
+
+}  // namespace
 
 int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int rows_on_device, void* stream) {
     MDR_REQUIRE(h != nullptr, "index handle is NULL");
@@ -673,24 +799,8 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
         rc = add_any(h, rows, src_dtype, n, h->ntotal, st);
         if (rc) return reject(rc);
     } else {
-        // chunked H2D through a device staging buffer (<= 256 MiB), converting straight into the shard
-        const long long chunk_rows = (long long)((256ull << 20) / row_src);
-        size_t need = (size_t)(n < chunk_rows ? n : chunk_rows) * row_src;
-        if (need > h->stage_bytes) {
-            if (h->stage) MDR_HIP_TRY(hipFree(h->stage));
-            h->stage = nullptr;
-            h->stage_bytes = 0;
-            MDR_HIP_TRY(hipMalloc(&h->stage, need));
-            h->stage_bytes = need;
-        }
-        for (long long r0 = 0; r0 < n; r0 += chunk_rows) {
-            long long nr = n - r0 < chunk_rows ? n - r0 : chunk_rows;
-            if (hipMemcpyAsync(h->stage, (const char*)rows + (size_t)r0 * row_src, (size_t)nr * row_src, hipMemcpyHostToDevice, st) != hipSuccess)
-                return reject(set_error(MDR_E_HIP, "hipMemcpyAsync(host rows) failed"));
-            rc = add_any(h, h->stage, src_dtype, nr, h->ntotal + r0, st);
-            if (rc) return reject(rc);
-            if (hipStreamSynchronize(st) != hipSuccess) return reject(set_error(MDR_E_HIP, "stream sync failed in add()"));  // staging buffer is reused; host buffer must be consumed before return
-        }
+        rc = upload_host_rows(h, (const char*)rows, n, src_dtype, row_src, st);
+        if (rc) return reject(rc);
     }
     int flag = 0;
     MDR_HIP_TRY(hipMemcpyAsync(&flag, h->flags, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -76,7 +76,7 @@ __device__ __forceinline__ void consider(float s, unsigned row, bool valid, floa
 #define MDR_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 // cache policy of the corpus stream (aux bits of global_load_lds: 0 = default, 2 = nt). The corpus is read once per
 // search and is 30x the Infinity Cache, so the stream is non-temporal: measured 1.698 vs 1.733 ms per 5M-row search
-// (interleaved A/B of two builds of these sources, gpurun_out r02a; scripts/gpu_ab.sh rebuilds the comparison).
+// (interleaved A/B of two builds of these sources, gpurun_out r02a; scripts/measure/gpu_ab.sh rebuilds the comparison).
 #ifndef MDR_MIPS_DMA_AUX
 #define MDR_MIPS_DMA_AUX 2
 #endif

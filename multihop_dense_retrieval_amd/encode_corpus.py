@@ -90,7 +90,7 @@ class DeviceStager:
     pinned host block per tensor and batch; batch shapes differ from batch to batch (every batch is padded to its own longest
     passage), so the caching allocators keep missing and the calls fall through to hipMalloc / hipHostMalloc / hipHostFree --
     measured on the box: 14-39 ms of host time per batch of ~5 MB with the GPU idle, i.e. the corpus encoder ran at 14 k passages/s
-    end to end against 30 k on the device (scripts/gpu_encode_corpus_probe.py). Here nothing is allocated in the steady state:
+    end to end against 30 k on the device (scripts/measure/gpu_encode_corpus_probe.py). Here nothing is allocated in the steady state:
     the tensors of a batch are packed into one pinned buffer (a host memcpy), go over in ONE asynchronous copy into a device buffer
     of the same layout, and the views handed to the model alias that buffer. Stream order protects the device buffer (the copy of
     batch i+1 is queued behind the forward of batch i); an event per pinned buffer protects the host side."""

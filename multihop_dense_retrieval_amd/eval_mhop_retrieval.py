@@ -192,7 +192,7 @@ def load_index(indexpath, d=768, storage="f32"):
         return np.ascontiguousarray(xb[lo:hi])
 
     kw = {"storage": "bf16"} if storage == "bf16" else {"storage": "compact"} if storage == "f32-compact" else {}
-    step = 1 << 18
+    step = 1 << 18 if use_side else 1 << 22  # fp32 map: the library pipelines the upload itself (pinned double buffer, copy stream): few, large calls
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         index = ShardedIndexFlatIP(d, n, local_index=IndexFlatIP(d, **kw))
         index.local.reserve(index.hi - index.lo)
