@@ -202,6 +202,15 @@ int mdr_assemble_hop2(const int64_t* q_ids_dev, const int64_t* q_mask_dev, int b
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Host array -> device buffer, pipelined (on-disk formats: the memory-mapped token arena and any other large host array) ==
+ *   batch_q_encodes = move_to_cuda(dict(batch_q_encodes))                    /root/reference/mdr/retrieval/utils/utils.py:24-41 (`.cuda()` of a host tensor)
+ * for arrays of gigabytes in PAGEABLE memory (np.load(mmap_mode="r") included): two pinned staging buffers are filled by parallel memcpy while the
+ * previous chunk crosses PCIe (the same pipeline mdr_index_add runs for host rows). Synchronises `stream` before it returns: the
+ * source may be unmapped and the destination read afterwards.
+ * ---------------------------------------------------------------------------------------------- */
+int mdr_upload_host(void* dst_dev, const void* src_host, size_t bytes, int device, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Test hook: one encoder GEMM in isolation, out[M, N] = epilogue(A[M, K] . W[N, K]^T + bias[N]) -- the torch.nn.Linear
  * inside HF RobertaModel's layers (the reference reaches them through model.encode_q, mhop_retriever.py:23-26).
  * A, W: f16 device, K-contiguous; bias f32. epilogue: 0 = bias -> f16 out, 1 = bias + erf-GELU -> f16 out,

@@ -29,17 +29,73 @@ def arena_tag(tokenizer, roberta, max_tokens):
             f"|empty_text_to_title={int(bool(roberta))}|max_tokens={max_tokens}")
 
 
+def _npz_memmap(path):
+    """{name: read-only np.memmap} over the members of an UNCOMPRESSED .npz (np.savez), or None when a member is compressed / not a plain array.
+    np.load(npz) reads every member into fresh memory (3.6 GB for a 5 M-passage arena: 1.2 s + the pageable upload); a map costs nothing until the
+    upload pipeline (mdr_upload_host) walks it."""
+    import struct
+    import zipfile
+    out = {}
+    try:
+        with zipfile.ZipFile(path) as zf, open(path, "rb") as f:
+            for info in zf.infolist():
+                if info.compress_type != zipfile.ZIP_STORED or not info.filename.endswith(".npy"):
+                    return None
+                f.seek(info.header_offset)
+                hdr = f.read(30)
+                if hdr[:4] != b"PK\x03\x04":
+                    return None
+                n_name, n_extra = struct.unpack("<HH", hdr[26:30])
+                start = info.header_offset + 30 + n_name + n_extra
+                f.seek(start)
+                version = np.lib.format.read_magic(f)
+                shape, fortran, dtype = np.lib.format.read_array_header_1_0(f) if version == (1, 0) else np.lib.format.read_array_header_2_0(f)
+                if fortran or dtype.hasobject:
+                    return None
+                name = info.filename[:-4]
+                if int(np.prod(shape)) == 0 or dtype.kind in "US":
+                    f.seek(start)
+                    out[name] = np.lib.format.read_array(f, allow_pickle=False)  # (the tag string, the empty `empty` array: tiny)
+                else:
+                    out[name] = np.memmap(path, dtype=dtype, mode="r", offset=f.tell(), shape=shape)
+    except (OSError, ValueError, zipfile.BadZipFile, struct.error):
+        return None
+    return out
+
+
+def _to_device(x, device, dtype):
+    """torch tensor (any device) or numpy array / memmap -> contiguous device tensor of `dtype`; big host arrays go through libmdrhip's pinned
+    double-buffer pipeline (mdr_upload_host) instead of a pageable `.to(device)`."""
+    if torch.is_tensor(x):
+        return x.to(device=device, dtype=dtype).contiguous()
+    x = np.ascontiguousarray(x) if not isinstance(x, np.memmap) else x
+    want = {torch.int32: np.int32, torch.int64: np.int64, torch.uint8: np.uint8}[dtype]
+    if x.dtype != want:
+        x = np.ascontiguousarray(x, dtype=want)
+    device = torch.device(device)
+    if device.type != "cuda":
+        return torch.from_numpy(np.array(x)).to(device)
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    out = torch.empty(x.shape, dtype=dtype, device=torch.device("cuda", dev_index))
+    if x.size:
+        _lib.check(_lib.lib().mdr_upload_host(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(x.ctypes.data), x.nbytes, dev_index,
+                                              _lib.current_stream_ptr(out.device)))
+    return out
+
+
 class TokenArena:
     def __init__(self, tokens, offsets, empty=None, bos_id=0, eos_id=2, pad_id=1):
-        self.tokens = tokens.to(dtype=torch.int32).contiguous()
-        self.offsets = offsets.to(dtype=torch.int64).contiguous()
-        self.empty = None if empty is None else empty.to(dtype=torch.uint8).contiguous()
+        """tokens / offsets / empty: torch tensors, or (from load(), lazily) numpy arrays / memmaps that only `.to(device)` turns into tensors."""
+        lazy = not torch.is_tensor(tokens)
+        self.tokens = tokens if lazy else tokens.to(dtype=torch.int32).contiguous()
+        self.offsets = offsets if lazy else offsets.to(dtype=torch.int64).contiguous()
+        self.empty = None if empty is None else (empty if lazy else empty.to(dtype=torch.uint8).contiguous())
         self.bos_id, self.eos_id, self.pad_id = bos_id, eos_id, pad_id
-        self.n_docs = int(self.offsets.numel()) - 1
+        self.n_docs = int(self.offsets.shape[0]) - 1
 
     def to(self, device):
-        return TokenArena(self.tokens.to(device), self.offsets.to(device), None if self.empty is None else self.empty.to(device),
-                          self.bos_id, self.eos_id, self.pad_id)
+        return TokenArena(_to_device(self.tokens, device, torch.int32), _to_device(self.offsets, device, torch.int64),
+                          None if self.empty is None else _to_device(self.empty, device, torch.uint8), self.bos_id, self.eos_id, self.pad_id)
 
     # -- builders ----------------------------------------------------------------------------------------
     @classmethod
@@ -82,15 +138,23 @@ class TokenArena:
 
     def save(self, path, tag=""):
         """np.savez appends ".npz" unless the name ends with it; `tag` (arena_tag) records what the tokens are valid for."""
+        path = os.fspath(path)
         final = path if path.endswith(".npz") else path + ".npz"
         tmp = final + f".tmp{os.getpid()}.npz"  # written under another name and renamed: a rank polling for the file never reads a partial one
-        np.savez(tmp, tokens=self.tokens.cpu().numpy(), offsets=self.offsets.cpu().numpy(),
-                 empty=(np.zeros(0, np.uint8) if self.empty is None else self.empty.cpu().numpy()), tag=np.array(str(tag)))
+        def host(x):
+            return x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+        np.savez(tmp, tokens=host(self.tokens), offsets=host(self.offsets),
+                 empty=(np.zeros(0, np.uint8) if self.empty is None else host(self.empty)), tag=np.array(str(tag)))
         os.replace(tmp, final)
 
     @classmethod
     def load(cls, path, expect_tag=None):
         """expect_tag: return None (caller rebuilds) when the file carries no tag or a different one."""
+        z = _npz_memmap(path)  # members mapped, not read: `.to(device)` streams them through the upload pipeline
+        if z is not None and {"tokens", "offsets", "empty"} <= set(z):
+            if expect_tag is not None and ("tag" not in z or str(z["tag"]) != str(expect_tag)):
+                return None
+            return cls(z["tokens"], z["offsets"], z["empty"] if z["empty"].size else None)
         z = np.load(path)
         if expect_tag is not None and ("tag" not in z.files or str(z["tag"]) != str(expect_tag)):
             return None

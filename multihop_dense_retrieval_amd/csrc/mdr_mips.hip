@@ -810,6 +810,47 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
     return MDR_OK;
 }
 
+int mdr_upload_host(void* dst_dev, const void* src_host, size_t bytes, int device, void* stream) {
+    MDR_REQUIRE(bytes == 0 || (dst_dev && src_host), "NULL pointer");
+    if (bytes == 0) return MDR_OK;
+    DeviceGuard g(device);
+    if (!g.ok) return set_error(MDR_E_HIP, "hipSetDevice(%d) failed", device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t chunk = 64ull << 20;
+    if (bytes <= (4ull << 20)) {  // small: one plain copy
+        MDR_HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
+        MDR_HIP_TRY(hipStreamSynchronize(st));
+        return MDR_OK;
+    }
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int rc = MDR_OK;
+    auto fail = [&](const char* what) { rc = set_error(MDR_E_HIP, "%s failed in mdr_upload_host", what); };
+    for (int i = 0; i < 2 && rc == MDR_OK; ++i) {
+        if (hipHostMalloc(&pin[i], chunk, hipHostMallocDefault) != hipSuccess) fail("hipHostMalloc");
+        else if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) fail("hipEventCreate");
+    }
+    unsigned hc = std::thread::hardware_concurrency();
+    const char* env = getenv("MDR_UPLOAD_THREADS");
+    const int nt = env ? (atoi(env) > 0 ? atoi(env) : 1) : (hc >= 16 ? 8 : hc >= 4 ? (int)hc / 2 : 1);
+    size_t off = 0;
+    for (long long c = 0; rc == MDR_OK && off < bytes; ++c) {
+        const int slot = (int)(c & 1);
+        const size_t len = bytes - off < chunk ? bytes - off : chunk;
+        if (c >= 2 && hipEventSynchronize(ev[slot]) != hipSuccess) { fail("hipEventSynchronize"); break; }  // the slot's previous copy has left the pinned buffer
+        parallel_copy((char*)pin[slot], (const char*)src_host + off, len, nt);
+        if (hipMemcpyAsync((char*)dst_dev + off, pin[slot], len, hipMemcpyHostToDevice, st) != hipSuccess) { fail("hipMemcpyAsync"); break; }
+        if (hipEventRecord(ev[slot], st) != hipSuccess) { fail("hipEventRecord"); break; }
+        off += len;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == MDR_OK) fail("hipStreamSynchronize");
+    for (int i = 0; i < 2; ++i) {
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+        if (pin[i]) (void)hipHostFree(pin[i]);
+    }
+    return rc;
+}
+
 int64_t mdr_index_ntotal(const mdr_index* h) { return h ? h->ntotal : 0; }
 int mdr_index_dim(const mdr_index* h) { return h ? h->d : 0; }
 int64_t mdr_index_stream_bytes(const mdr_index* h) { return h ? (int64_t)((h->ntotal + 15) / 16 * 16) * (int64_t)h->d * (is_bf16(h) ? 2 : 4) : 0; }

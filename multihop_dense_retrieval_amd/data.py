@@ -39,6 +39,60 @@ def truncate_longest_first_2_11(la, lb, budget):
 PREFIX_SPACE_2_11 = True
 
 
+class _LightBPE:
+    """The part of a HF RoBERTa tokenizer this package uses -- BPE ids of plain texts, the three special ids, the vocabulary -- straight on the
+    `tokenizers` backend of the saved `tokenizer.json` (the HF class of transformers >= 4 is a wrapper around exactly this object: same ids,
+    tests/test_tokenizer_fidelity.py). Importing `transformers.AutoTokenizer` costs the drop-in CLI 0.8-2.5 s of its start-up; this costs 1 ms.
+    Anything else a HF tokenizer can do (special tokens, truncation, padding) raises: the callers apply the 2.11 rules themselves (tokenize_2_11)."""
+
+    def __init__(self, path, cfg):
+        import tokenizers
+        self._tk = tokenizers.Tokenizer.from_file(path)
+        self._tk.no_padding()
+        self._tk.no_truncation()
+
+        def tid(key, default):
+            t = cfg.get(key, default)
+            t = t.get("content", default) if isinstance(t, dict) else t
+            i = self._tk.token_to_id(t)
+            if i is None:
+                raise ValueError(f"{key} {t!r} is not in the vocabulary of {path}")
+            return i
+        self.bos_token_id, self.eos_token_id, self.pad_token_id = tid("bos_token", "<s>"), tid("eos_token", "</s>"), tid("pad_token", "<pad>")
+
+    def __call__(self, texts, add_special_tokens=False, truncation=False, **kw):
+        if add_special_tokens or truncation or kw:
+            raise TypeError("the light tokenizer only supplies BPE ids (add_special_tokens=False, truncation=False); load the HF class for anything else")
+        if isinstance(texts, str):
+            return {"input_ids": self._tk.encode(texts, add_special_tokens=False).ids}
+        return {"input_ids": [e.ids for e in self._tk.encode_batch(list(texts), add_special_tokens=False)]}
+
+    def get_vocab(self):
+        return self._tk.get_vocab()
+
+    def __len__(self):
+        return self._tk.get_vocab_size()
+
+
+def load_tokenizer(model_name):
+    """`AutoTokenizer.from_pretrained(args.model_name)` (eval_mhop_retrieval.py:81) for the eval CLI. A LOCAL directory that holds a `tokenizer.json` of a
+    RoBERTa-family tokenizer is opened with the `tokenizers` backend alone (_LightBPE, under the HF class's own name: the token-arena tag and
+    is_roberta_family see the same class name); everything else -- hub names, slow tokenizers, other families, MDR_LIGHT_TOKENIZER=0 -- goes to transformers."""
+    import os
+    tj, tc = os.path.join(model_name, "tokenizer.json"), os.path.join(model_name, "tokenizer_config.json")
+    if os.environ.get("MDR_LIGHT_TOKENIZER", "1") != "0" and os.path.isfile(tj) and os.path.isfile(tc):
+        try:
+            with open(tc) as f:
+                cfg = json.load(f)
+            name = str(cfg.get("tokenizer_class", ""))
+            if "Roberta" in name:
+                return type(name, (_LightBPE,), {})(tj, cfg)
+        except (OSError, ValueError, ImportError):
+            pass
+    from transformers import AutoTokenizer
+    return AutoTokenizer.from_pretrained(model_name)
+
+
 def is_roberta_family(tokenizer):
     return "Roberta" in tokenizer.__class__.__name__
 

@@ -83,6 +83,13 @@ def _setup_logging():
 def _load_config(model_name):
     """HF config from a local directory when one is given, roberta-base constants otherwise."""
     if os.path.isdir(model_name):
+        # `AutoConfig.from_pretrained(args.model_name)` (reference :80) reads <dir>/config.json; only the geometry is used here, so the file is read
+        # directly (importing transformers costs the CLI 0.8-2.5 s of start-up; RobertaConfig ignores the keys it does not know)
+        try:
+            with open(os.path.join(model_name, "config.json")) as f:
+                return RobertaConfig(**json.load(f))
+        except (OSError, ValueError, TypeError):
+            pass
         try:
             from transformers import AutoConfig
             return AutoConfig.from_pretrained(model_name)
@@ -243,8 +250,8 @@ def main(argv=None, tokenizer=None):
         logger.setLevel(logging.WARNING)
     # the tokenizer and its worker processes come FIRST: the workers are forked before this process touches the device
     if tokenizer is None:
-        from transformers import AutoTokenizer
-        tokenizer = AutoTokenizer.from_pretrained(args.model_name)
+        from .data import load_tokenizer
+        tokenizer = load_tokenizer(args.model_name)  # AutoTokenizer.from_pretrained, or the same BPE without importing transformers (data._LightBPE)
     from .pipeline import TokenizerPool
     pool = TokenizerPool(tokenizer, args.num_workers)
     _mark("tokenizer_and_workers")

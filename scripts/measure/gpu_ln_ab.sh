@@ -10,7 +10,7 @@ for v in "$@"; do
   python - "$S" "$v" <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'layernorm_kernel' in r['Name']:
-        print(f"{sys.argv[2]:24s} layernorm calls {int(r['Calls']):5d} avg {float(r['AverageNs'])/1e3:8.2f} us  max {float(r['MaxNs'])/1e3:8.2f}")
+    if 'layernorm_kernel' in r['Name'] or 'gemm_quad' in r['Name']:
+        print(f"{sys.argv[2]:24s} {r['Name'][:44]:44s} calls {int(r['Calls']):5d} avg {float(r['AverageNs'])/1e3:8.2f} us  max {float(r['MaxNs'])/1e3:8.2f}")
 PY
 done

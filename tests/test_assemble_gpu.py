@@ -66,5 +66,9 @@ def test_arena_from_corpus_and_roundtrip(tmp_path):
     a = TokenArena.from_corpus(id2doc, Tok())
     assert a.offsets.tolist() == [0, 3, 6, 7] and a.empty.tolist() == [0, 1, 0] and a.tokens.tolist() == [4, 5, 6, 7, 8, 7, 4]
     a.save(tmp_path / "arena.npz")
-    b = TokenArena.load(tmp_path / "arena.npz")
-    assert torch.equal(a.tokens, b.tokens) and torch.equal(a.offsets, b.offsets) and torch.equal(a.empty, b.empty)
+    b = TokenArena.load(tmp_path / "arena.npz").to("cuda")  # load() maps the members; .to() sends them through mdr_upload_host
+    assert torch.equal(a.tokens, b.tokens.cpu()) and torch.equal(a.offsets, b.offsets.cpu()) and torch.equal(a.empty, b.empty.cpu())
+    big = TokenArena(torch.arange(5_000_011, dtype=torch.int32) % 50265, torch.tensor([0, 5_000_011]), None)  # > 4 MiB: the pinned double-buffer path
+    big.save(tmp_path / "big.npz")
+    c = TokenArena.load(tmp_path / "big.npz").to("cuda")
+    assert c.tokens.dtype == torch.int32 and torch.equal(c.tokens.cpu(), big.tokens) and c.empty is None

@@ -270,7 +270,7 @@ def test_arena_cache_is_rebuilt_when_its_tokenisation_rule_differs(tmp_path, tin
     path = str(tmp_path / "c.json.arena.npz")
     a.save(path, tag=tag)
     b = TokenArena.load(path, expect_tag=tag)
-    assert b is not None and np.array_equal(b.tokens.numpy(), a.tokens.numpy()) and np.array_equal(b.offsets.numpy(), a.offsets.numpy()) and b.empty.tolist() == [0, 1]
+    assert b is not None and np.array_equal(np.asarray(b.tokens), a.tokens.numpy()) and np.array_equal(np.asarray(b.offsets), a.offsets.numpy()) and b.empty.tolist() == [0, 1]  # (load(): memory-mapped members)
     assert TokenArena.load(path, expect_tag=arena_tag(tok, True, 350)) is None          # another token cap
     assert TokenArena.load(path, expect_tag=arena_tag(tok, False, 40)) is None          # another empty-text rule
     old = data.PREFIX_SPACE_2_11
@@ -311,3 +311,37 @@ def test_index_numerics_mismatch_warns(tmp_path, caplog):
     with caplog.at_level(logging.WARNING):
         assert ev.check_index_numerics(idx, types.SimpleNamespace(residual_fp32=2)) == 0
     assert "residual_fp32=0" in caplog.text and "MDR_RESIDUAL_FP32=0" in caplog.text
+
+
+def test_arena_npz_members_are_memory_mapped_and_round_trip(tmp_path):
+    """TokenArena.load maps the members of the uncompressed .npz (no 3.6 GB read at 5 M passages); the mapped arrays equal what np.load returns,
+    a stale tag still returns None, and a compressed file falls back to np.load."""
+    from multihop_dense_retrieval_amd import arena
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 40, 500)
+    offs = np.zeros(501, np.int64)
+    offs[1:] = np.cumsum(lens)
+    toks = rng.integers(3, 500, int(offs[-1])).astype(np.int32)
+    empty = (rng.random(500) < 0.1).astype(np.uint8)
+    a = arena.TokenArena(torch.from_numpy(toks), torch.from_numpy(offs), torch.from_numpy(empty))
+    p = str(tmp_path / "c.arena.npz")
+    a.save(p, tag="T1")
+    z = arena._npz_memmap(p)
+    assert isinstance(z["tokens"], np.memmap) and isinstance(z["offsets"], np.memmap) and str(z["tag"]) == "T1"
+    ref = np.load(p)
+    for k in ("tokens", "offsets", "empty"):
+        assert np.array_equal(np.asarray(z[k]), ref[k]) and z[k].dtype == ref[k].dtype
+    b = arena.TokenArena.load(p, expect_tag="T1")
+    assert b.n_docs == 500 and not torch.is_tensor(b.tokens) and np.array_equal(np.asarray(b.tokens), toks)
+    assert arena.TokenArena.load(p, expect_tag="T2") is None
+    c = b.to("cpu")  # (the device path, through mdr_upload_host, is exercised by tests/test_assemble_gpu.py)
+    assert torch.is_tensor(c.tokens) and c.tokens.dtype == torch.int32 and np.array_equal(c.tokens.numpy(), toks) and np.array_equal(c.empty.numpy(), empty)
+    b.save(str(tmp_path / "again.npz"), tag="T1")  # a lazily loaded arena can be written back
+    assert np.array_equal(np.load(str(tmp_path / "again.npz"))["tokens"], toks)
+    a2 = arena.TokenArena(torch.from_numpy(toks), torch.from_numpy(offs), None)
+    a2.save(str(tmp_path / "noempty.npz"), tag="T1")
+    assert arena.TokenArena.load(str(tmp_path / "noempty.npz"), expect_tag="T1").empty is None
+    np.savez_compressed(str(tmp_path / "z.npz"), tokens=toks, offsets=offs, empty=empty, tag=np.array("T1"))
+    assert arena._npz_memmap(str(tmp_path / "z.npz")) is None
+    d = arena.TokenArena.load(str(tmp_path / "z.npz"), expect_tag="T1")
+    assert torch.is_tensor(d.tokens) and np.array_equal(d.tokens.numpy(), toks)

@@ -286,3 +286,39 @@ def test_token_ids_equal_transformers_2_11_when_the_golden_file_exists():
         assert np.array_equal(np.asarray(e["input_ids"]), np.asarray(g[key]["input_ids"])), key
     ids, _ = encode_pairs_2_11(tok, [d["title"].strip() for d in g["docs"]], [(d["text"].strip() or d["title"]) for d in g["docs"]], 300, False)
     assert ids == g["ctx"]
+
+
+def test_light_tokenizer_is_the_hf_tokenizer_without_transformers(tmp_path, tiny_roberta_tokenizer):
+    """data.load_tokenizer opens a local RoBERTa tokenizer.json on the `tokenizers` backend alone (start-up: the transformers import is 0.8-2.5 s):
+    same BPE ids, same special ids, same vocabulary, same class NAME (token-arena tag, is_roberta_family), same 2.11-rule encodings."""
+    import numpy as np
+    from multihop_dense_retrieval_amd import data
+    from multihop_dense_retrieval_amd.arena import arena_tag
+    d = tmp_path / "toy-roberta"
+    tiny_roberta_tokenizer.save_pretrained(str(d))
+    light = data.load_tokenizer(str(d))
+    hf = tiny_roberta_tokenizer
+    assert isinstance(light, data._LightBPE) and light.__class__.__name__ == hf.__class__.__name__ and data.is_roberta_family(light)
+    assert (light.bos_token_id, light.eos_token_id, light.pad_token_id) == (hf.bos_token_id, hf.eos_token_id, hf.pad_token_id) == (0, 2, 1)
+    assert light.get_vocab() == hf.get_vocab() and len(light) == len(hf)
+    assert arena_tag(light, True, 350) == arena_tag(hf, True, 350)
+    texts = ["Who directed the film that starred the actor born in 1950 in Lyon", " leading space", "Zürich 3.14 — naïve café", "", "   ", "a" * 300,
+             "The 2012 Summer Olympics were held in London; the stadium seats 80,000 people."]
+    assert light(texts, add_special_tokens=False, truncation=False)["input_ids"] == hf(texts, add_special_tokens=False, truncation=False)["input_ids"]
+    assert light(texts[0], add_special_tokens=False)["input_ids"] == hf(texts[0], add_special_tokens=False)["input_ids"]
+    for L in (12, 40):
+        a, b = data.tokenize_2_11(light, texts, None, L), data.tokenize_2_11(hf, texts, None, L)
+        assert all(np.array_equal(a[k].numpy(), b[k].numpy()) for k in ("input_ids", "attention_mask"))
+        pairs = [(texts[0], t) for t in texts]
+        a, b = data.tokenize_2_11(light, None, pairs, L), data.tokenize_2_11(hf, None, pairs, L)
+        assert all(np.array_equal(a[k].numpy(), b[k].numpy()) for k in ("input_ids", "attention_mask"))
+    import pytest
+    with pytest.raises(TypeError):
+        light(texts, add_special_tokens=True)
+    # anything that is not a local RoBERTa tokenizer.json goes to transformers
+    import os
+    os.environ["MDR_LIGHT_TOKENIZER"] = "0"
+    try:
+        assert not isinstance(data.load_tokenizer(str(d)), data._LightBPE)
+    finally:
+        del os.environ["MDR_LIGHT_TOKENIZER"]
