@@ -114,7 +114,9 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
 int mdr_index_search_telemetry(const mdr_index* h, int nq, int k, const void* workspace_dev, int64_t* out4_host, void* stream);
 
 /* Test hook: force a kernel variant (0 = auto, 1 = generic fp32 reference kernel, 2 = exact MFMA stream kernel,
- * 3 = screen + exact refinement, 4 = the same without the int8 screening tier in front of the fp16 hi-plane screen). */
+ * 3 = screen + exact refinement, 4 = the same without the int8 screening tier in front of the fp16 hi-plane screen, 5 = the screen path with the
+ * GEMM-structured screen-k pass (csrc/mdr_mips_gemmk.inl; slower than the default 32-queries-per-wave kernel, kept with its parity test) for groups of 256
+ * queries, 2 <= k <= 256). */
 int mdr_index_set_variant(mdr_index* h, int variant);
 /* Name of the kernel the last search dispatched to (for rocprof matching); static storage. */
 const char* mdr_index_last_kernel(const mdr_index* h);

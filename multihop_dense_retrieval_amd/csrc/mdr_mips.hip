@@ -47,6 +47,7 @@ namespace {
 #include "mdr_mips_exact.inl"
 #include "mdr_mips_screen_fp16.inl"
 #include "mdr_mips_generic.inl"
+#include "mdr_mips_gemmk.inl"
 #include "mdr_mips_screen_i8.inl"
 #include "mdr_mips_merge.inl"
 
@@ -100,11 +101,11 @@ bool wants_i8(const mdr_index* h) {
 }
 
 int grow(mdr_index* h, long long need_rows, hipStream_t st) {
-    long long need = pad32(need_rows);
+    long long need = (need_rows + 255) / 256 * 256;  // whole 256-row tiles (mips_gemmk_kernel reads tiles; a multiple of 32 as every other kernel expects)
     if (need <= h->cap_rows) return MDR_OK;
     long long ncap = need;  // first reservation is exact; later ones grow by 1.5x
     if (h->cap_rows) {
-        long long geo = pad32(h->cap_rows + h->cap_rows / 2);
+        long long geo = (h->cap_rows + h->cap_rows / 2 + 255) / 256 * 256;
         if (geo > ncap) ncap = geo;
     }
     const size_t nbytes = (size_t)ncap * plane_bytes_per_row(h);
@@ -244,6 +245,13 @@ bool is_bf16(const mdr_index* h) { return h->storage == MDR_STORE_BF16; }
 bool wide_pass(int nq) {
     static const bool off = getenv("MDR_MIPS_WIDE") && atoi(getenv("MDR_MIPS_WIDE")) == 0;
     return !off && nq > kStreamQ;
+}
+// The GEMM-structured main pass of the beam > 1 search (mdr_mips_gemmk.inl) is a MEASURED NEGATIVE of round 5 (four versions, 2.7-2.9 ms per 256-query pass at
+// 5 M rows where mips_screenk32_kernel takes 2.3-2.4; NEGATIVE_RESULTS round 5): it runs only when asked for -- test-hook variant 5 (the parity test keeps it
+// honest: same lists, same bits) or MDR_MIPS_GEMMK=1 (A/B runs).
+bool gemmk_on(const mdr_index* h) {
+    static const bool env_on = getenv("MDR_MIPS_GEMMK") && atoi(getenv("MDR_MIPS_GEMMK")) == 1;
+    return env_on || h->variant == 5;
 }
 bool stream_kernel_supports(const mdr_index* h, int k) { return !is_bf16(h) && h->d == 768 && k <= 128; }
 bool screen_kernel_supports(const mdr_index* h, int k) { return h->d == 768 && k <= 256; }
@@ -554,6 +562,8 @@ int run_screenk32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_de
     const size_t merge_lds = (size_t)kMergeKLds * 8;
     int rc_ = ensure_dynamic_lds((const void*)mips_screen32_kernel<NKB, 2, BF>, (int)lds_bytes);
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screenk32_kernel<NKB, BF>, (int)lds_bytes);
+    constexpr size_t gemmk_lds = (4 + 4) * 16 * kFragBytes + kWideQ * 8;  // four row-fragment + four query-fragment slots of 16 KiB, list counters, thresholds
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_gemmk_kernel<BF>, (int)gemmk_lds);
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen_kernel<NKB, 2, BF>, (int)lds_bytes);
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screenk_kernel<NKB, BF>, (int)lds_bytes);
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)merge_screenk_kernel<BF>, (int)merge_lds);
@@ -588,8 +598,12 @@ int run_screenk32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_de
             hipLaunchKernelGGL((mips_screen32_kernel<NKB, 2, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg, nqg,
                                gi * kWideQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, stages);
             hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G * stages, k, tg, qcap);
-            hipLaunchKernelGGL((mips_screenk32_kernel<NKB, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg,
-                               (const float*)tg, nqg, cand, cnt, k, sctl);
+            if (gemmk_on(h) && h->ntotal >= 256ll * p.G)  // round 5 (not the default: see gemmk_on): the main pass as a 256 x 256 x 64 GEMM with the screen as its epilogue (mdr_mips_gemmk.inl)
+                hipLaunchKernelGGL((mips_gemmk_kernel<BF>), dim3(p.G), dim3(512), gemmk_lds, st, (const char*)h->hi, (long long)h->ntotal, qg, bg, (const float*)tg, nqg,
+                                   cand, cnt, sctl);
+            else
+                hipLaunchKernelGGL((mips_screenk32_kernel<NKB, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg,
+                                   (const float*)tg, nqg, cand, cnt, k, sctl);
         }
         hipLaunchKernelGGL((merge_screenk_kernel<BF>), dim3(nqg), dim3(256), merge_lds, st, (const u64*)cand, (const int*)cnt, p.G, k, bg, (const char*)h->hi,
                            (const char*)h->lo, h->nkb, q_dev + (size_t)gi * kWideQ * h->d, D_dev + (size_t)gi * kWideQ * k,
@@ -857,7 +871,8 @@ int64_t mdr_index_stream_bytes(const mdr_index* h) { return h ? (int64_t)((h->nt
 
 int mdr_index_set_variant(mdr_index* h, int variant) {
     MDR_REQUIRE(h != nullptr, "index handle is NULL");
-    MDR_REQUIRE(variant >= 0 && variant <= 4, "variant must be 0 (auto), 1 (generic), 2 (exact stream), 3 (screen + refine) or 4 (screen + refine without the int8 tier)");
+    MDR_REQUIRE(variant >= 0 && variant <= 5, "variant must be 0 (auto), 1 (generic), 2 (exact stream), 3 (screen + refine), 4 (screen + refine without the int8 tier) or "
+                                              "5 (screen path with the GEMM-structured screen-k pass for groups of 256 queries: a measured negative kept for its parity test)");
     h->variant = variant;
     return MDR_OK;
 }
@@ -990,7 +1005,8 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
         if (wide_pass(nq)) {
             rc = bf ? run_screenk32<true>(h, p, ws, q_dev, nq, k, qhi, D_dev, I_ll, id_offset, st)
                     : run_screenk32<false>(h, p, ws, q_dev, nq, k, qhi, D_dev, I_ll, id_offset, st);
-            h->last_kernel = bf ? "mips_screenk32_kernel<24,bf16>" : "mips_screenk32_kernel<24>";
+            if (gemmk_on(h) && h->ntotal >= 256ll * p.G) h->last_kernel = bf ? "mips_gemmk_kernel<bf16>" : "mips_gemmk_kernel";
+            else h->last_kernel = bf ? "mips_screenk32_kernel<24,bf16>" : "mips_screenk32_kernel<24>";
         } else {
             rc = bf ? run_screenk<true>(h, p, ws, q_dev, nq, k, qhi, D_dev, I_ll, id_offset, st)
                     : run_screenk<false>(h, p, ws, q_dev, nq, k, qhi, D_dev, I_ll, id_offset, st);

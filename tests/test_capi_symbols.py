@@ -48,7 +48,7 @@ def test_product_library_holds_no_measurement_code():
     blob = open(path, "rb").read()
     for knob in (b"MDR_GEMM_ABL", b"MDR_GEMM_EPI", b"MDR_I8_ABL", b"MDR_ATTN_ABL", b"g_gemm_stamp", b"g_i8_stamp", b"g_attn_stamp"):
         assert knob not in blob, f"{knob!r} found in the product library"
-    allowed = {"MDR_GEMM_CFG", "MDR_MIPS_WIDE", "MDR_MIPS_I8", "MDR_UPLOAD_THREADS"}  # (the last: memcpy threads of the host-upload pipeline)
+    allowed = {"MDR_GEMM_CFG", "MDR_MIPS_WIDE", "MDR_MIPS_I8", "MDR_MIPS_GEMMK", "MDR_UPLOAD_THREADS"}  # (the last: memcpy threads of the host-upload pipeline)
     seen = set()
     for src in glob.glob(os.path.join(ROOT, "multihop_dense_retrieval_amd", "csrc", "*")):
         seen |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(src).read()))
