@@ -676,13 +676,18 @@ void parallel_copy(char* dst, const char* src, size_t bytes, int nt) {
     if (nt <= 1 || bytes < (8u << 20)) { memcpy(dst, src, bytes); return; }
     std::vector<std::thread> th;
     const size_t part = (bytes / (size_t)nt + 4095) & ~(size_t)4095;
+    size_t done_to = part < bytes ? part : bytes;  // [0, part) is this thread's; a part whose thread cannot be started (resource limits) is copied here too
     for (int t = 1; t < nt; ++t) {
         const size_t lo = (size_t)t * part;
         if (lo >= bytes) break;
         const size_t len = bytes - lo < part ? bytes - lo : part;
-        th.emplace_back([=] { memcpy(dst + lo, src + lo, len); });
+        try {
+            th.emplace_back([=] { memcpy(dst + lo, src + lo, len); });
+        } catch (...) {  // std::system_error: no more threads -- nothing may throw across the C ABI
+            memcpy(dst + lo, src + lo, len);
+        }
     }
-    memcpy(dst, src, part < bytes ? part : bytes);
+    memcpy(dst, src, done_to);
     for (auto& t : th) t.join();
 }
 
@@ -728,7 +733,7 @@ int upload_host_rows(mdr_index* h, const char* rows, long long n, int src_dtype,
     bool abort_flag = false;
     int producer_rc = MDR_OK;
     const int device = h->device;
-    std::thread producer([&] {
+    auto produce = [&] {
         if (hipSetDevice(device) != hipSuccess) { std::lock_guard<std::mutex> g(mu); producer_rc = MDR_E_HIP; abort_flag = true; cv.notify_all(); return; }
         for (long long c = 0; c < nchunks; ++c) {
             const int slot = (int)(c & 1);
@@ -749,7 +754,21 @@ int upload_host_rows(mdr_index* h, const char* rows, long long n, int src_dtype,
             copied = c + 1;
             cv.notify_all();
         }
-    });
+    };
+    std::thread producer;
+    try {
+        producer = std::thread(produce);
+    } catch (...) {  // no thread to be had: the same chunks, one after the other, on this thread (nothing may throw across the C ABI)
+        int rc_s = MDR_OK;
+        for (long long c = 0; c < nchunks && rc_s == MDR_OK; ++c) {
+            const long long r0 = c * chunk_rows, nr = n - r0 < chunk_rows ? n - r0 : chunk_rows;
+            memcpy(h->pin[0], rows + (size_t)r0 * row_src, (size_t)nr * row_src);
+            if (hipMemcpyAsync(h->stage, h->pin[0], (size_t)nr * row_src, hipMemcpyHostToDevice, st) != hipSuccess) { rc_s = set_error(MDR_E_HIP, "hipMemcpyAsync(host rows) failed"); break; }
+            rc_s = add_any(h, h->stage, src_dtype, nr, h->ntotal + r0, st);
+            if (rc_s == MDR_OK && hipStreamSynchronize(st) != hipSuccess) rc_s = set_error(MDR_E_HIP, "stream sync failed in add()");
+        }
+        return rc_s;
+    }
     int rc = MDR_OK;
     for (long long c = 0; c < nchunks && rc == MDR_OK; ++c) {
         const int slot = (int)(c & 1);
