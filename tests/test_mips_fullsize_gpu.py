@@ -400,3 +400,36 @@ def test_queries_far_outside_fp16_range(mdr, oracle, q_scale):
     assert idx.telemetry(70, 1)["bad_query"] == 1
     keep = torch.arange(70, device="cuda") != 3
     assert torch.equal(I[keep], base[1][1][keep])
+
+
+def test_config4_shard_shape_6_25m_bf16_rows_800_queries_k100(mdr):
+    """BASELINE configs[4] as ONE of its 8 shards sees it, at full size (this check lived in profiles/ only): 6.25 M x 768 bf16 rows,
+    800 queries (beam 8 x 100 questions: three passes of 256 + a 32-query remainder pass), k = 100. Size-independent properties -- planted rows found
+    first, scores sorted, every returned score equal to the fp64 product with the bf16-rounded row, no row anywhere beating the returned k-th (brute
+    force over all 25 chunks for a sample of the queries) -- plus the telemetry that the screen, not the exact fallback, decided."""
+    n_chunks, nq, k = 25, 800, 100
+    idx = mdr.IndexFlatIP(D_, storage="bf16")
+    idx.reserve(n_chunks * CHUNK)
+    for c in range(n_chunks):
+        idx.add(chunk(c))
+    assert idx.ntotal == 6_250_000
+    g = torch.Generator(device="cuda").manual_seed(404)
+    q = torch.randn((nq, D_), generator=g, device="cuda")
+    planted = (torch.arange(nq, device="cuda") * 7_793 + 31) % 6_250_000
+    rows = torch.stack([chunk(int(p) // CHUNK)[int(p) % CHUNK] for p in planted[:24].tolist()])
+    q[:24] = rows + 0.05 * q[:24]
+    D, I = idx.search_device(q.contiguous(), k)
+    assert "mips_screenk32_kernel" in idx.last_kernel()
+    t = idx.telemetry(nq, k)
+    assert t["path"] == 3 and t["fallback"] == 0, t
+    print(f"configs[4] shard shape, 6.25 M bf16 rows, nq {nq} k {k}: candidates per query {t['candidates'] / nq:.0f}")
+    assert torch.equal(I[:24, 0], planted[:24])
+    assert bool((D[:, :-1] >= D[:, 1:]).all()) and bool((I >= 0).all()) and bool((I < 6_250_000).all())
+    assert bool((I.sort(1).values[:, 1:] != I.sort(1).values[:, :-1]).all())  # k distinct rows per query
+    sample = torch.cat([torch.arange(0, 24, device="cuda"), torch.arange(24, nq, 97, device="cuda")])  # the planted queries + every 97th
+    ex = exact_scores(q[sample], I[sample], bf16_round)
+    assert float((ex - D[sample].double()).abs().max()) <= 2e-3
+    bs, bi = brute_force(q[sample], n_chunks, k, bf16_round)
+    assert float((bs[:, k - 1] - D[sample][:, k - 1]).max()) <= 2e-3  # nothing anywhere beats the returned k-th
+    differ = bi != I[sample]
+    assert bool(((bs - D[sample]).abs()[differ] <= 2e-3).all()) and float(differ.float().mean()) <= 0.05
