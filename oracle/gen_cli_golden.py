@@ -61,7 +61,9 @@ DUPLICATE_ROWS = ((100, 73), (201, 175))  # xb[100] = xb[73], xb[201] = xb[175] 
 # supporting titles by question number mod 4: chosen among the passages the toy encoder retrieves most, so that every metric takes both values
 SP_BY_RESIDUE = (["T173", "T58"], ["T173", "T213"], ["T58", "T-absent"], None)
 # (beam, topk, corpus-dict shape, extra flags).  (50, 50): the reference's own downstream setting (README.md:240-241 b50_k50), JSONL kept as a hash.
-CASES = [(1, 1, "list", []), (3, 4, "list", []), (5, 2, "dict", []), (3, 4, "dict", ["--only-eval-ans"]), (50, 50, "list", [])]
+# (100, 100): README.md:241 b100_k100, on the first N_Q_SMALL questions only (a 100 x 100 beam grid per question: the capture stays small).
+CASES = [(1, 1, "list", []), (3, 4, "list", []), (5, 2, "dict", []), (3, 4, "dict", ["--only-eval-ans"]), (50, 50, "list", []), (100, 100, "dict", ["small"])]
+N_Q_SMALL = 5
 
 
 def tiny_tokenizer():
@@ -118,12 +120,17 @@ def build_assets(out_dir):
     raw = os.path.join(out_dir, "qas.json")
     with open(raw, "w") as f:
         f.write("\n".join(json.dumps(q) for q in qs))
-    return {"tok": tok, "geom": geom, "sd": sd, "model_dir": model_dir, "ckpt": ckpt, "index": index_path, "xb": xb, "id2doc": paths, "raw": raw,
+    raw_small = os.path.join(out_dir, "qas_small.json")
+    with open(raw_small, "w") as f:
+        f.write("\n".join(json.dumps(q) for q in qs[:N_Q_SMALL]))
+    return {"tok": tok, "geom": geom, "sd": sd, "model_dir": model_dir, "ckpt": ckpt, "index": index_path, "xb": xb, "id2doc": paths, "raw": raw, "raw_small": raw_small,
             "questions": qs, "docs": docs}
 
 
 def cli_argv(a, beam, topk, shape, extra, save):
-    return [a["raw"], a["index"], a["id2doc"][shape], a["ckpt"], "--batch-size", str(BATCH), "--beam-size", str(beam), "--topk", str(topk),
+    small = "small" in extra  # (not a flag of the script: selects the short question file)
+    extra = [e for e in extra if e != "small"]
+    return [a["raw_small"] if small else a["raw"], a["index"], a["id2doc"][shape], a["ckpt"], "--batch-size", str(BATCH), "--beam-size", str(beam), "--topk", str(topk),
             "--model-name", a["model_dir"], "--gpu", "--shared-encoder", "--save-path", save, "--max-q-len", str(MAX_Q_LEN),
             "--max-q-sp-len", str(MAX_Q_SP_LEN)] + list(extra)
 

@@ -47,7 +47,7 @@ def _same_up_to_ties(got, want_titles, id2doc):
     return True
 
 
-@pytest.mark.parametrize("ci", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("ci", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("impl", ["product", "restatement"])
 def test_host_loop_reproduces_the_reference_scripts_own_run(golden, assets, ci, impl):
     meta, z = golden("cli_ref.json"), golden("cli_ref.npz")
@@ -55,6 +55,8 @@ def test_host_loop_reproduces_the_reference_scripts_own_run(golden, assets, ci, 
     beam, topk, ans_mode = case["beam"], case["topk"], "--only-eval-ans" in case["extra_flags"]
     raw = json.load(open(assets["id2doc"][case["id2doc_shape"]]))
     items = assets["questions"]
+    if "small" in case["extra_flags"]:  # the b100_k100 case runs on the first few questions (a 100 x 100 beam grid each)
+        items = items[:gen_cli_golden.N_Q_SMALL]
     if ans_mode:
         items = [it for it in items if it["answer"][0] not in ["yes", "no"]]
     if impl == "product":
