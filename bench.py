@@ -118,6 +118,9 @@ def parse():
     ap.add_argument("--cli-keep", action="store_true", help="--mode cli: keep the synthetic assets (and reuse the ones a previous --cli-keep run left in --cli-dir when rows / questions match)")
     ap.add_argument("--cli-workers", type=int, default=16, help="--mode cli: the CLI's --num-workers (tokenizer worker processes; the flag's default is the reference's 10)")
     ap.add_argument("--cli-legs", default="default,device", help="--mode cli: which flag sets to run: default = the reference's flags, device = --hop2-on-device, unfused = --no-pipeline-batches")
+    ap.add_argument("--lane-cus", type=int, default=0,
+                    help="CU-partitioned encoder lanes (round 5 experiment): the side lane (next batch's hop-1 forward) gets this many CUs (multiple of 8), the hop-2 "
+                         "forward the rest; 0 = both lanes may use every CU")
     ap.add_argument("--pool", type=int, default=16,
                     help="DIFFERENT question batches the timed steps cycle through (different lengths -> different hop-1 answers -> 19-22 k hop-2 tokens per batch "
                          "on the synthetic corpus); 1 = every step re-runs one batch (rounds 1-3)")
@@ -690,6 +693,8 @@ def main():
                                 max_q_len=args.max_q_len, max_q_sp_len=args.max_q_sp_len,
                                 use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank, world=world, weak=weak,
                                 pipelined=False if args.sequential else (2 if args.loop == "deep" else True), pool=args.pool, hop1_group=args.hop1_group)
+    if pipe.encoder is not None and args.lane_cus > 0:
+        pipe.encoder.partition_lanes(args.lane_cus)
     if pipe.encoder is not None and args.hop1_group > 1:
         pipe.encoder.capture_on_first_use = True  # a grouped hop-1 shape recurs only every G-th step: capture it at its first sighting (in the warm-up)
     out, elapsed = timed_steps(pipe, args, world, device, dist)
@@ -723,7 +728,7 @@ def main():
                                f"{B}-question batches{' per GPU (global batch ' + str(GB) + ')' if weak else ''}, 2-hop beam={args.beam} topk={args.topk}"
                                f"{' , MIPS-only (no encoder)' if not pipe.use_encoder else ', RoBERTa-base encoder (random init)'}",
                    "rows": N, "dim": d, "batch": B, "global_batch": GB, "beam": args.beam, "topk": args.topk, "shards": world,
-                   "collective_world_size": (dist.get_world_size() if dist is not None else 1), "collective_backend": (dist.get_backend() if dist is not None else None),
+                   "lane_cus": args.lane_cus, "collective_world_size": (dist.get_world_size() if dist is not None else 1), "collective_backend": (dist.get_backend() if dist is not None else None),
                    "encoder": pipe.encoder_desc(), "index_build_s": round(build_s, 2),
                    "loop": ("software-pipelined, two batches deep: hop 2 of batch i beside hop 1 of batch i+2 (two concurrent encoder forwards, two lanes / streams), "
                             "their ONE fused corpus pass on a third stream beside the encoder forwards of step i+1, path ranking behind it (every batch still walks "

@@ -21,6 +21,8 @@
 //                                       S = QK^T on MFMA, fp32 softmax in registers, O = PV on MFMA
 //   layernorm                           fp32 [T,H] -> fp16 (hidden state) or fp32 (final embedding)
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
 #include <algorithm>
 #include <type_traits>
 
@@ -63,6 +65,10 @@ struct mdr_encoder {
     _Float16* wproj = nullptr;
     float *bproj = nullptr, *lnp_g = nullptr, *lnp_b = nullptr;
     float fill_hint = 0.f;  // expected (tokens / (batch * seq_len)) of the next forwards; 0 = unknown (2/3 is assumed)
+    // CUs a forward may use = the CU mask of the stream it is enqueued on (hipExtStreamCreateWithCUMask; an ordinary stream: all of them). Cached per
+    // stream: the query is made at the first (warm-up) call on a stream, never inside a graph capture of a later one.
+    std::mutex cu_mu;
+    std::map<hipStream_t, int> stream_cus;
 };
 
 namespace {
@@ -412,6 +418,28 @@ int mdr_test_attn_stamps(unsigned long long* out_host, int max_wgs) {
 }
 #endif
 
+int mdr_stream_create_cu_range(int device, int cu_lo, int cu_hi, void** stream_out) {
+    MDR_REQUIRE(stream_out != nullptr, "stream_out is NULL");
+    DeviceGuard guard(device);
+    if (!guard.ok) return set_error(MDR_E_HIP, "hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    MDR_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int n = prop.multiProcessorCount;
+    MDR_REQUIRE(cu_lo >= 0 && cu_hi <= n && cu_hi - cu_lo >= 8 && cu_lo % 8 == 0 && cu_hi % 8 == 0, "CU range [%d, %d) must be multiples of 8 inside [0, %d)", cu_lo,
+                cu_hi, n);
+    std::vector<uint32_t> mask((size_t)(n + 31) / 32, 0u);
+    for (int i = cu_lo; i < cu_hi; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    hipStream_t st = nullptr;
+    MDR_HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    *stream_out = (void*)st;
+    return MDR_OK;
+}
+
+int mdr_stream_destroy(void* stream) {
+    if (stream) MDR_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return MDR_OK;
+}
+
 int mdr_encoder_set_fill_hint(mdr_encoder* h, float fill) {
     MDR_REQUIRE(h != nullptr, "encoder handle is NULL");
     MDR_REQUIRE(fill >= 0.f && fill <= 1.f, "fill must be in [0, 1] (0 = unknown)");
@@ -451,7 +479,22 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
     const int Tcap = B * L;
     // tile-shape heuristics only: the packed token count is known on the device; the host may pass what it expects
     const int Test = h->fill_hint > 0.f ? std::max(1, (int)(h->fill_hint * (float)Tcap)) : Tcap - Tcap / 3;
-    const int ncu = h->num_cus;
+    int ncu = h->num_cus;
+    {  // CU-partitioned lanes (round 5): the persistent GEMMs size their grids for the CUs THIS stream may run on
+        std::lock_guard<std::mutex> lk(h->cu_mu);
+        auto it = h->stream_cus.find(st);
+        if (it != h->stream_cus.end()) ncu = it->second;
+        else {
+            uint32_t mask[32] = {0};
+            int n = 0;
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone && hipExtStreamGetCUMask(st, 32, mask) == hipSuccess)
+                for (uint32_t w_ : mask) n += __builtin_popcount(w_);
+            else (void)hipGetLastError();
+            if (n >= 8 && n <= h->num_cus) ncu = n / 8 * 8;
+            if (cs == hipStreamCaptureStatusNone) h->stream_cus[st] = ncu;
+        }
+    }
     const long long* ids = (const long long*)ids_dev;
     const long long* mask = (const long long*)mask_dev;
 

@@ -152,9 +152,50 @@ class _HipRobertaEncoder:
             st = self._lanes[lane] = _Lane()
         return st
 
+    def partition_lanes(self, side_cus):
+        """CU-partitioned lanes (round 5): lane 1 (the short forward of the pipelined loop) gets the last `side_cus` CUs of the device, lane 0 the rest; each
+        lane's forwards run on its own CU-masked stream (mdr_stream_create_cu_range) whatever stream the caller is on (events order them with the caller's
+        stream). side_cus = 0 removes the partition. Captured graphs are dropped: a capture freezes grid sizes."""
+        for s_ in getattr(self, "_lane_streams", {}).values():
+            _lib.check(_lib.lib().mdr_stream_destroy(ctypes.c_void_p(s_[1])))
+        self._lane_streams = {}
+        for st in self._lanes.values():
+            st.graphs.clear()
+        side_cus = int(side_cus)
+        if side_cus <= 0:
+            return
+        n = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if side_cus % 8 or not 8 <= side_cus <= n - 8:
+            raise ValueError(f"side_cus must be a multiple of 8 in [8, {n - 8}]")
+        for lane, (lo, hi) in ((0, (0, n - side_cus)), (1, (n - side_cus, n))):
+            ptr = ctypes.c_void_p()
+            _lib.check(_lib.lib().mdr_stream_create_cu_range(self.device.index or 0, lo, hi, ctypes.byref(ptr)))
+            self._lane_streams[lane] = (torch.cuda.ExternalStream(ptr.value, device=self.device), ptr.value)
+
+    def lane_stream(self, lane):
+        s_ = getattr(self, "_lane_streams", {}).get(lane)
+        return None if s_ is None else s_[0]
+
     def encode_seq(self, input_ids, mask, lane=0):
         """lane: which workspace / graph cache this call uses. Calls on DIFFERENT lanes may overlap on different streams (the
         pipelined retrieval loop encodes the next batch's questions beside the current batch's hop-2 inputs)."""
+        ls = self.lane_stream(lane)
+        if ls is not None and torch.cuda.current_stream(self.device) != ls:
+            # this lane owns a CU-masked stream: run there, ordered behind what the caller's stream holds, and let the caller's stream wait for the result
+            cur = torch.cuda.current_stream(self.device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            ls.wait_event(ev)
+            with torch.cuda.stream(ls):
+                out = self.encode_seq(input_ids, mask, lane)
+                done = torch.cuda.Event()
+                done.record(ls)
+            for t in (input_ids, mask):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(ls)
+            cur.wait_event(done)
+            out.record_stream(cur)
+            return out
         if not self._h.value:
             raise RuntimeError("encoder has no weights on a device: call load_saved(...)/load_state_dict(...) and .to('cuda') first")
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
@@ -224,7 +265,8 @@ class _HipRobertaEncoder:
                 self._forward_into(sid, smk, sout, lane)  # warm-up: sizes the workspace, sets kernel attributes
                 torch.cuda.synchronize(self.device)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                ls = self.lane_stream(lane)  # a CU-masked lane stream: capture ON it (the library sizes its grids by the capturing stream's CUs)
+                with (torch.cuda.graph(graph, stream=ls) if ls is not None else torch.cuda.graph(graph)):
                     self._forward_into(sid, smk, sout, lane)
             finally:
                 _lib.check(_lib.lib().mdr_encoder_set_fill_hint(self._h, 0.0))

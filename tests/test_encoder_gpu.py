@@ -210,6 +210,33 @@ def test_large_batch_kernels_agree_with_small_batch_path(models):
     assert err.max().item() <= 1e-6
 
 
+def test_cu_partitioned_lanes_return_the_same_bits(models):
+    """mdr_stream_create_cu_range + RobertaRetriever.partition_lanes (round 5; a measured negative for the headline loop, kept as an option): a forward
+    on a CU-masked lane stream sizes its persistent grids for that stream's CUs and returns the embeddings of the unpartitioned forward, bit for bit, on
+    both lanes, eagerly and from a replayed graph."""
+    m, _ = models["base"]
+    B, L = 80, 320
+    g = torch.Generator(device="cuda").manual_seed(22)
+    lens = torch.randint(L // 2, L + 1, (B,), generator=g, device="cuda")
+    ids = torch.randint(3, seeded.ROBERTA_BASE["vocab"], (B, L), generator=g, device="cuda")
+    mask = (torch.arange(L, device="cuda")[None, :] < lens[:, None]).long()
+    ids = torch.where(mask.bool(), ids, torch.ones_like(ids))
+    ids[:, 0] = 0
+    ref = m.encode_q(ids, mask, None)
+    ref_small = m.encode_q(ids[:7, :40].contiguous(), mask[:7, :40].contiguous(), None, lane=1)
+    try:
+        m.partition_lanes(64)
+        assert m.lane_stream(0) is not None and m.lane_stream(1) is not None
+        for rep in range(3):  # eager, capture, replay
+            assert torch.equal(m.encode_q(ids, mask, None), ref), rep
+            assert torch.equal(m.encode_q(ids[:7, :40].contiguous(), mask[:7, :40].contiguous(), None, lane=1), ref_small), rep
+        with pytest.raises(ValueError):
+            m.partition_lanes(12)
+    finally:
+        m.partition_lanes(0)
+    assert m.lane_stream(0) is None and torch.equal(m.encode_q(ids, mask, None), ref)
+
+
 def test_attention_query_block_boundaries(models):
     """Sequence lengths around the attention kernel's block structure -- query blocks of 128 (128 / 129 / 130: one vs two blocks; 256 / 257: two vs
     three), key jobs of 96 through the LDS ring (95 / 96 / 97: one vs two jobs, a ragged last pair-tile; 160 / 161: a job of exactly two pair-tiles vs one
