@@ -68,6 +68,9 @@ def expected_state_dict_shapes(config, with_pooler=True):
     return sd
 
 
+_CU_RANGE_STREAMS = {}  # (device, cu_lo, cu_hi) -> (torch.cuda.ExternalStream, raw pointer); process lifetime (see partition_lanes)
+
+
 class _Lane:
     def __init__(self):
         self.ws = None
@@ -156,8 +159,8 @@ class _HipRobertaEncoder:
         """CU-partitioned lanes (round 5): lane 1 (the short forward of the pipelined loop) gets the last `side_cus` CUs of the device, lane 0 the rest; each
         lane's forwards run on its own CU-masked stream (mdr_stream_create_cu_range) whatever stream the caller is on (events order them with the caller's
         stream). side_cus = 0 removes the partition. Captured graphs are dropped: a capture freezes grid sizes."""
-        for s_ in getattr(self, "_lane_streams", {}).values():
-            _lib.check(_lib.lib().mdr_stream_destroy(ctypes.c_void_p(s_[1])))
+        # (the masked streams are never destroyed: torch's caching allocator keeps per-stream state for every stream a tensor was allocated on, and a
+        #  graph's private pool outlives the capture -- a destroyed stream under either is a crash at some later free. They are cached per CU range.)
         self._lane_streams = {}
         for st in self._lanes.values():
             st.graphs.clear()
@@ -168,9 +171,12 @@ class _HipRobertaEncoder:
         if side_cus % 8 or not 8 <= side_cus <= n - 8:
             raise ValueError(f"side_cus must be a multiple of 8 in [8, {n - 8}]")
         for lane, (lo, hi) in ((0, (0, n - side_cus)), (1, (n - side_cus, n))):
-            ptr = ctypes.c_void_p()
-            _lib.check(_lib.lib().mdr_stream_create_cu_range(self.device.index or 0, lo, hi, ctypes.byref(ptr)))
-            self._lane_streams[lane] = (torch.cuda.ExternalStream(ptr.value, device=self.device), ptr.value)
+            key = (self.device.index or 0, lo, hi)
+            if key not in _CU_RANGE_STREAMS:
+                ptr = ctypes.c_void_p()
+                _lib.check(_lib.lib().mdr_stream_create_cu_range(key[0], lo, hi, ctypes.byref(ptr)))
+                _CU_RANGE_STREAMS[key] = (torch.cuda.ExternalStream(ptr.value, device=self.device), ptr.value)
+            self._lane_streams[lane] = _CU_RANGE_STREAMS[key]
 
     def lane_stream(self, lane):
         s_ = getattr(self, "_lane_streams", {}).get(lane)
