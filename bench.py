@@ -99,7 +99,7 @@ def parse():
     ap.add_argument("--sequential", action="store_true",
                     help="one batch at a time (hop-1 encode, search, hop-2 encode, search as four dependent stages). Default: the "
                          "software-pipelined loop -- hop 2 of batch i beside hop 1 of batch i+1: two concurrent encoder forwards (two lanes / streams) + one fused corpus pass")
-    ap.add_argument("--loop", choices=["deep", "pipelined"], default="pipelined",
+    ap.add_argument("--loop", choices=["deep", "pipelined", "shift"], default="pipelined",
                     help="pipelined (default): hop 2 of batch i beside hop 1 of batch i+1, then their ONE corpus pass; deep: two batches in flight -- the corpus pass "
                          "of step i (hop 2 of batch i + hop 1 of batch i+2) on its own stream beside the encoder forwards of step i+1. Measured round 4: 14.91 k vs "
                          "14.87 k queries/s -- both kernels fill every CU, the pass takes 1.55 instead of 1.12 ms and the encoder stage 6.58 instead of 5.54 (DESIGN.md)")
@@ -692,7 +692,7 @@ def main():
     pipe = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device,
                                 max_q_len=args.max_q_len, max_q_sp_len=args.max_q_sp_len,
                                 use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank, world=world, weak=weak,
-                                pipelined=False if args.sequential else (2 if args.loop == "deep" else True), pool=args.pool, hop1_group=args.hop1_group)
+                                pipelined=False if args.sequential else (2 if args.loop == "deep" else 3 if args.loop == "shift" else True), pool=args.pool, hop1_group=args.hop1_group)
     if pipe.encoder is not None and args.lane_cus > 0:
         pipe.encoder.partition_lanes(args.lane_cus)
     if pipe.encoder is not None and args.hop1_group > 1:

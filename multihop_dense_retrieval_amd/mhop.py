@@ -142,6 +142,8 @@ class SyntheticTwoHop:
         self.use_encoder = use_encoder
         self.pipelined = bool(pipelined)
         self.deep = pipelined == 2 or pipelined == "deep"  # two batches deep: the corpus pass on its own stream beside the next step's encoders
+        self.shift = pipelined == 3 or pipelined == "shift"  # round 5: the hop-1 forward of batch i+2 beside the corpus pass of step i (not beside the hop-2 forward)
+        self._shift_q = None  # shift mode: (embeddings of the next batch's questions, event) -- encoded beside the previous pass, searched in the coming one
         self._ready = collections.deque()  # pipelined mode: (q, D, I) of the upcoming batches whose hop 1 is already done, in order
         self.hop1_group = max(1, int(hop1_group))  # pipelined mode: the hop-1 forward encodes the questions of this many future batches at once
         self._deep = collections.deque()  # deep mode: (q, D, I, event) of the two batches whose hop 1 is done or in flight
@@ -432,7 +434,75 @@ class SyntheticTwoHop:
         self._cur = (self._cur + 1) % self.pool
         return {"q": q, "q2": q2o, "D": D, "I": I, "D2": D2, "I2": I2, "hop1": h1, "hop2": h2, "score": sc, "ids2": ids, "mask2": mask}
 
+    # -- hop 1 beside the corpus pass ------------------------------------------------------------------------------------------------
+    def _step_shift(self):
+        """_step_pipelined with the small forward moved: there the next batch's hop-1 forward (~84 short kernels) runs beside the hop-2 forward, whose
+        persistent one-workgroup-per-CU GEMMs own every CU -- each short kernel waits for one of them to end and delays the next one by its own duration
+        (0.74 ms of a 5.4 ms encoder stage). Here the hop-2 forward of batch i runs ALONE; the hop-1 forward of batch i+2 starts when it ends, on the
+        side stream, beside the fused corpus pass of step i (hop 2 of batch i + hop 1 of batch i+1, whose embeddings were produced beside the pass of
+        step i-1). An HBM / int8-MFMA-bound pass and a latency-bound small forward share the chip instead of two fp16-MFMA forwards. What spills over the
+        end of the pass overlaps the next hop-2 forward as before. Same arithmetic per question; only the order of independent batches changes."""
+        B, bm = self.B, self.beam
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main, side = torch.cuda.current_stream(), self._side
+        if not self._ready:  # prologue: hop 1 of the first batch plainly; the second batch's questions encoded, to be searched in the first fused pass
+            self._ready.append(self._hop1_only())
+            nb = self._nxt()
+            qn = self._encode(nb["q_ids"], nb["q_mask"], lane=1) if self.use_encoder else self.planted_rows + nb["noise"]
+            e0 = torch.cuda.Event()
+            e0.record()
+            self._shift_q = (qn, e0)
+            self._search_ev = self._search_ev[:-1] if self._search_ev else self._search_ev
+        q, D, I = self._ready.popleft()
+        ev = [self._mark()]
+        ev.append(ev[0])
+        ev.append(ev[0])
+        nb2 = self.batches[(self._cur + 2) % self.pool]
+        if self.use_encoder:
+            ids, mask = self._hop2_inputs(I, D)
+            ev.append(self._mark())
+            q2 = self._encode(ids, mask)
+            enc_done = torch.cuda.Event()
+            enc_done.record()
+            side.wait_event(enc_done)  # the small forward starts when the large one has ended
+            with torch.cuda.stream(side):
+                q_nn = self._encode(nb2["q_ids"], nb2["q_mask"], lane=1)
+                done = torch.cuda.Event()
+                done.record()
+            nb2["q_ids"].record_stream(side)
+            nb2["q_mask"].record_stream(side)
+        else:
+            ids = mask = None
+            ev.append(self._mark())
+            q2 = (0.5 * q).repeat_interleave(bm, 0) + self.table[(I.reshape(-1) % 1024)]
+            q_nn, done = self.planted_rows + nb2["noise"], None
+        ev.append(self._mark())
+        q_next, ready_ev = self._shift_q
+        main.wait_event(ready_ev)
+        q_next.record_stream(main)
+        e = torch.cat([q2, q_next], 0)
+        Dc, Ic = self._search(e.contiguous(), bm)
+        q2 = e[:B * bm]
+        D2, I2 = Dc[:B * bm].contiguous(), Ic[:B * bm].contiguous()
+        self._ready.append((e[B * bm:], Dc[B * bm:].contiguous(), Ic[B * bm:].contiguous()))
+        ev.append(self._mark())
+        h1, h2, sc = rank_paths_device(D, I, D2, I2, bm, self.topk)
+        ev.append(self._mark())
+        if done is None:
+            done = torch.cuda.Event()
+            done.record()
+        self._shift_q = (q_nn, done)
+        self._ev.append(ev)
+        self.step_log.append((self._cur, mask.sum(1) if mask is not None else None))
+        self._cur = (self._cur + 1) % self.pool
+        return {"q": q, "q2": q2, "D": D, "I": I, "D2": D2, "I2": I2, "hop1": h1, "hop2": h2, "score": sc, "ids2": ids, "mask2": mask}
+
     def step(self):
+        if self.shift:
+            if self.world > 1:
+                raise NotImplementedError("--loop shift is a one-rank experiment")
+            return self._step_shift()
         if self.deep:
             return self._step_deep()
         if self.pipelined:
