@@ -129,3 +129,24 @@ def test_the_capture_exercises_what_it_claims(golden):
     assert all(v == {0, 1} for v in vals.values()), vals  # every metric takes both values somewhere
     assert {m["ans_recall"] for m in meta["cases"][3]["metrics"]} == {0, 1} and len(meta["cases"][3]["metrics"]) == 17
     assert any(q.endswith("?") for q in meta["cases"][0]["questions_encoded"])  # the "??" question kept one
+
+
+def test_the_generators_2_11_tokenizer_adapter_and_the_products_tokenisation_agree(assets):
+    """Two independent restatements of transformers 2.11's `batch_encode_plus(..., pad_to_max_length=True)` for RoBERTa: the adapter the reference script ran
+    under in oracle/gen_cli_golden.py (per-segment prefix space, literal one-token-at-a-time `longest_first` pop loop) and the product's data.tokenize_2_11
+    (closed-form truncation, numpy padding). Same ids and masks on the toy questions and on every (question, passage) pair the script built, at even and odd
+    token budgets and at budgets that force ties between the two segments."""
+    from multihop_dense_retrieval_amd import data
+    tok = assets["tok"]
+    adapter = gen_cli_golden.Tokenizer211(tok, gen_cli_golden.Capture())
+    qs = [mhop.strip_question(q["question"]) for q in assets["questions"]]
+    docs = [d["text"] if d["text"].strip() else d["title"] for d in assets["docs"][:60]]
+    for L in (8, 12, 13, 40, 41, 70):
+        a = adapter.batch_encode_plus(qs, max_length=L, pad_to_max_length=True, return_tensors="pt")
+        b = data.tokenize_2_11(tok, qs, None, L)
+        assert torch.equal(a["input_ids"], b["input_ids"]) and torch.equal(a["attention_mask"], b["attention_mask"]), L
+    pairs = [(qs[i % len(qs)], docs[(7 * i) % len(docs)]) for i in range(90)] + [(qs[0], ""), ("", docs[0]), (qs[1], qs[1])]
+    for L in (9, 16, 17, 39, 40, 41, 64, 350):
+        a = adapter.batch_encode_plus(pairs, max_length=L, pad_to_max_length=True, return_tensors="pt")
+        b = data.tokenize_2_11(tok, None, pairs, L)
+        assert torch.equal(a["input_ids"], b["input_ids"]) and torch.equal(a["attention_mask"], b["attention_mask"]), L
