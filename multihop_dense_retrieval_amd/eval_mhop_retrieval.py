@@ -146,9 +146,14 @@ def wait_for_file(ready, target, what, timeout=None, poll=0.2, beat=30.0):
     import time
     timeout = float(os.environ.get("MDR_SHARED_FILE_TIMEOUT", 6 * 3600)) if timeout is None else timeout
     t0 = last = time.monotonic()
+    try:  # a marker an EARLIER job left behind is not this job's failure: only one written since this process started counts
+        import psutil
+        born = psutil.Process().create_time() - 1.0
+    except Exception:
+        born = time.time() - 1.0
     while not ready():
         now = time.monotonic()
-        if os.path.exists(target + ".failed"):
+        if os.path.exists(target + ".failed") and os.path.getmtime(target + ".failed") >= born:
             raise RuntimeError(f"rank 0 failed to build {what} ({target}): {open(target + '.failed').read().strip()}")
         if now - t0 > timeout:
             raise RuntimeError(f"gave up waiting for {what} ({target}) after {timeout:.0f} s: is rank 0 alive?")

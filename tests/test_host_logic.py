@@ -2,6 +2,7 @@
 against the frozen restatement of the reference's inline code (tests/golden/mhop.json, from
 oracle/mhop_oracle.py) and against outputs of the reference's own functions (tests/golden/collate.npz)."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -295,8 +296,12 @@ def test_wait_for_file_deadline_heartbeat_and_failure_marker(tmp_path, caplog):
             raise ValueError("disk full")
     with pytest.raises(RuntimeError, match="rank 0 failed to build the thing.*disk full"):
         ev.wait_for_file(lambda: False, target, "the thing", timeout=5, poll=0.05)
+    os.utime(target + ".failed", (1.0, 1.0))  # a marker from an earlier job (older than this process) is ignored: the wait runs into its deadline instead
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        ev.wait_for_file(lambda: False, target, "the thing", timeout=0.2, poll=0.05)
     with ev._failure_marker(target):  # a later successful build clears the marker
         pass
+    assert not os.path.exists(target + ".failed")
     ev.wait_for_file(lambda: True, target, "the thing", timeout=1)
 
 
