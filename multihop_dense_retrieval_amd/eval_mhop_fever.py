@@ -47,6 +47,17 @@ def build_parser():
     return p
 
 
+class fever_docs_view:
+    """`id2doc[str(id)]` of the FEVER corpus dict ([title, text, is_intro] lists, :79) as the {"title", "text"} mapping mhop.build_hop2_pairs reads."""
+
+    def __init__(self, id2doc):
+        self.id2doc = id2doc
+
+    def __getitem__(self, key):
+        v = self.id2doc[key]
+        return {"title": v[0], "text": v[1]}
+
+
 def fever_record(item, chains, id2doc, title2doc):
     """{id, claim, candidate_chains: [[(title, text), (title, text)], ...]} with the text looked up BY TITLE (:161-169)."""
     out = []
@@ -74,6 +85,7 @@ def main(argv=None, tokenizer=None):
     with open(args.corpus_dict) as f:
         id2doc = json.load(f)
     title2doc = {item[0]: item[1] for item in id2doc.values()}
+    docs_view = fever_docs_view(id2doc)
     logger.info(f"Corpus size {len(id2doc)}")
 
     logger.info("Loading trained model...")
@@ -97,14 +109,8 @@ def main(argv=None, tokenizer=None):
             q_embeds = model.encode_q(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids", None))
             D, I = index.search(q_embeds, b1)
             D, I = D.cpu().numpy(), I.cpu().numpy()
-            pairs = []
-            for b_idx in range(len(batch_q)):
-                for j, doc_id in enumerate(I[b_idx]):
-                    doc = id2doc[str(int(doc_id))][1]
-                    if doc.strip() == "":  # ("roberta" in model_name is always true here)
-                        doc = id2doc[str(int(doc_id))][0]
-                        D[b_idx][j] = float("-inf")
-                    pairs.append((batch_q[b_idx], doc))
+            # (claim, passage) pairs with the empty-passage rule (:115-122) -- the same lines as the HotpotQA script's, on list-valued entries
+            pairs = mhop.build_hop2_pairs(batch_q, D, I, docs_view, roberta=True)  # ("roberta" in model_name is always true here)
             enc2 = move_to_cuda(dict(_tokenize(tokenizer, None, pairs, args.max_q_sp_len)))
             q_sp_embeds = model.encode_q(enc2["input_ids"], enc2["attention_mask"], enc2.get("token_type_ids", None))
             D_, I_ = index.search(q_sp_embeds, b2)

@@ -27,6 +27,9 @@ The model is the reference's own `RobertaRetriever` (mdr/retrieval/models/mhop_r
 (mdr/retrieval/utils/utils.py:10-22) from a checkpoint derived from oracle/seeded.py, so the GPU test can rebuild the very same assets on the GPU
 box from (seed, name, shape) + tests/golden/tiny_bpe and compare the drop-in CLI's chains with the captured ones.
 
+The FEVER variant (scripts/eval/eval_mhop_fever.py, SURVEY.md section 8(f) rank 4) is executed the same way (`run_reference_fever`: its own code object, the same stubs;
+its final write to a directory on its author's machine fails here as it does everywhere else, after `retrieval_outputs` has been filled).
+
 Assets (`build_assets`, shared with the tests -- it needs only numpy / torch / transformers, not the reference): 257 passages, four with empty
 text, three with identical embeddings (exact path-score ties), 23 questions (one ending in `??`, one without `?`, five yes/no answers), a list-valued
 and a dict-valued corpus dict, a 2-layer 768-wide checkpoint with the `module.` prefix, corpus embeddings = seeded normals.
@@ -120,10 +123,14 @@ def build_assets(out_dir):
     raw = os.path.join(out_dir, "qas.json")
     with open(raw, "w") as f:
         f.write("\n".join(json.dumps(q) for q in qs))
+    claims = [{"id": 1000 + i, "claim": q["question"].rstrip("?"), "label": "SUPPORTS" if i % 2 else "REFUTES"} for i, q in enumerate(qs)]
+    raw_fever = os.path.join(out_dir, "claims.json")
+    with open(raw_fever, "w") as f:
+        f.write("\n".join(json.dumps(c) for c in claims))
     raw_small = os.path.join(out_dir, "qas_small.json")
     with open(raw_small, "w") as f:
         f.write("\n".join(json.dumps(q) for q in qs[:N_Q_SMALL]))
-    return {"tok": tok, "geom": geom, "sd": sd, "model_dir": model_dir, "ckpt": ckpt, "index": index_path, "xb": xb, "id2doc": paths, "raw": raw, "raw_small": raw_small,
+    return {"tok": tok, "geom": geom, "sd": sd, "model_dir": model_dir, "ckpt": ckpt, "index": index_path, "xb": xb, "id2doc": paths, "raw": raw, "raw_small": raw_small, "raw_fever": raw_fever, "claims": claims,
             "questions": qs, "docs": docs}
 
 
@@ -254,6 +261,51 @@ def run_reference(argv):
     return g, cap, err.getvalue()
 
 
+FEVER_SCRIPT = os.path.join(REF, "scripts", "eval", "eval_mhop_fever.py")
+FEVER_CASES = [(2, 5, 6), (3, 2, 4)]  # (--beam-size-1, --beam-size-2, --topk)
+
+
+def fever_argv(a, b1, b2, topk, save):
+    return [a["raw_fever"], a["index"], a["id2doc"]["list"], a["ckpt"], "--batch-size", str(BATCH), "--beam-size-1", str(b1), "--beam-size-2", str(b2),
+            "--topk", str(topk), "--model-name", a["model_dir"], "--gpu", "--shared-encoder", "--save-path", save, "--max-q-len", str(MAX_Q_LEN),
+            "--max-q-sp-len", str(MAX_Q_SP_LEN)]
+
+
+def run_reference_fever(argv):
+    """The reference's scripts/eval/eval_mhop_fever.py executed as __main__ under the same library stubs. It imports `models.*` / `utils.*` relative to
+    mdr/retrieval, and its LAST statement writes to a directory on its author's machine (`/private/home/...`, :172), which fails everywhere else: the script's
+    own code object is therefore exec'd in a namespace this function keeps, so that `retrieval_outputs` (:159-169, filled before that write) survives it."""
+    import logging
+    import torch
+    cap = Capture()
+    err = io.StringIO()
+    root_logger = logging.getLogger()
+    keep = (root_logger.level, list(root_logger.handlers))
+    pkg = os.path.join(REF, "mdr", "retrieval")
+    clash = {k: sys.modules.pop(k) for k in list(sys.modules) if k in ("models", "utils") or k.startswith("models.") or k.startswith("utils.")}
+    sys.path.insert(0, pkg)
+    ns = {"__name__": "__main__", "__file__": FEVER_SCRIPT}
+    try:
+        with stubbed(cap), contextlib.redirect_stderr(err), contextlib.redirect_stdout(io.StringIO()):
+            import utils.utils as fever_utils  # the module object THIS script imports move_to_cuda from
+            fever_utils.move_to_cuda = lambda sample: sample
+            sys.argv = [FEVER_SCRIPT] + argv
+            torch.manual_seed(0)
+            try:
+                exec(compile(open(FEVER_SCRIPT).read(), FEVER_SCRIPT, "exec"), ns)
+                raise AssertionError("the hard-coded output directory exists here?")
+            except FileNotFoundError as e:
+                assert "/private/home" in str(e), e
+    finally:
+        sys.path.remove(pkg)
+        for k in [k for k in sys.modules if k in ("models", "utils") or k.startswith("models.") or k.startswith("utils.")]:
+            del sys.modules[k]
+        sys.modules.update(clash)
+        root_logger.handlers[:] = keep[1]
+        root_logger.setLevel(keep[0])
+    return ns, cap, err.getvalue()
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="mdr_cli_golden_")
     a = build_assets(tmp)
@@ -290,6 +342,23 @@ def main():
         print(f"case {ci}: beam {beam} topk {topk} {shape} {extra}: {len(g['metrics'])} metrics, {len(jsonl)} JSONL bytes, "
               f"{n_inf} empty passages in hop-1 beams, log tail: {log[-1]!r}")
     assert any(c["empty_passages_in_hop1_beams"] for c in meta["cases"]), "no case exercised the empty-passage rule: change the seed"
+    # ---- the FEVER variant (scripts/eval/eval_mhop_fever.py: separate hop widths, list-valued corpus dict, (title, text) chains looked up BY TITLE) ----
+    meta["fever_cases"] = []
+    for fi, (b1, b2, topk) in enumerate(FEVER_CASES):
+        ns, cap, err = run_reference_fever(fever_argv(a, b1, b2, topk, "fever_out.jsonl"))
+        n_batches = -(-len(ns["questions"]) // BATCH)
+        assert len(cap.searches) == 2 * n_batches and len(ns["retrieval_outputs"]) == len(a["claims"])
+        lines = [json.dumps(r) for r in ns["retrieval_outputs"]]
+        meta["fever_cases"].append({"beam1": b1, "beam2": b2, "topk": topk, "n_batches": n_batches, "jsonl": "".join(ln + "\n" for ln in lines),
+                                    "hop2_pairs": [cap.tokenizer_calls[2 * b + 1] for b in range(n_batches)],
+                                    "log": [ln for ln in err.split("\n") if ln != "" and "Loading weights" not in ln]})
+        n_inf = 0
+        for b in range(n_batches):
+            h1, h2 = cap.searches[2 * b], cap.searches[2 * b + 1]
+            arrays[f"f{fi}.b{b}.D"], arrays[f"f{fi}.b{b}.I"] = h1["D"], h1["I"].astype(np.int32)
+            arrays[f"f{fi}.b{b}.D2"], arrays[f"f{fi}.b{b}.I2"] = h2["D"], h2["I"].astype(np.int32)
+            n_inf += sum(int(i) in EMPTY_DOCS for i in h1["I"].ravel())
+        print(f"fever case {fi}: beam {b1} x {b2} topk {topk}: {len(lines)} records, {sum(map(len, lines))} JSONL bytes, {n_inf} empty passages in hop-1 beams")
     with open(os.path.join(GOLD, "cli_ref.json"), "w") as f:
         json.dump(meta, f, indent=1, ensure_ascii=False)
     np.savez_compressed(os.path.join(GOLD, "cli_ref.npz"), **arrays)

@@ -134,3 +134,24 @@ def test_cli_only_eval_ans_against_the_reference_scripts_run(golden, assets, tmp
     if agree == 17:
         tail = case["log"][case["log"].index("Evaluating 17 samples..."):]
         assert [ln for ln in err.split("\n") if ln][-len(tail):] == tail
+
+
+@pytest.mark.parametrize("fi", [0, 1])
+def test_fever_cli_chains_against_the_reference_fever_scripts_run(golden, assets, tmp_path, fi):
+    """The FEVER drop-in on the rebuilt toy assets against what the reference's eval_mhop_fever.py computed (fp32 on the CPU, under library stubs): same
+    records except where two path scores are closer than the fp16-operand noise of the HIP encoder; the log lines are the script's."""
+    from multihop_dense_retrieval_amd import eval_mhop_fever
+    meta = golden("cli_ref.json")
+    case = meta["fever_cases"][fi]
+    save = str(tmp_path / "fever.jsonl")
+    argv = gen_cli_golden.fever_argv(assets, case["beam1"], case["beam2"], case["topk"], save)
+    recs = eval_mhop_fever.main(argv, tokenizer=assets["tok"])
+    got = open(save).read().split("\n")[:-1]
+    want = case["jsonl"].split("\n")[:-1]
+    assert len(got) == len(want) == 23 == len(recs)
+    equal = sum(a == b for a, b in zip(got, want))
+    top_equal = sum(json.loads(a)["candidate_chains"][0] == json.loads(b)["candidate_chains"][0] for a, b in zip(got, want))
+    r0 = json.loads(got[0])
+    assert list(r0.keys()) == ["id", "claim", "candidate_chains"] and len(r0["candidate_chains"]) == case["topk"] and r0["id"] == 1000
+    print(f"fever case {fi} beam {case['beam1']} x {case['beam2']} topk {case['topk']}: records byte-equal {equal}/23, best chain equal {top_equal}/23")
+    assert top_equal >= 21 and equal >= 19
