@@ -27,6 +27,8 @@ The model is the reference's own `RobertaRetriever` (mdr/retrieval/models/mhop_r
 (mdr/retrieval/utils/utils.py:10-22) from a checkpoint derived from oracle/seeded.py, so the GPU test can rebuild the very same assets on the GPU
 box from (seed, name, shape) + tests/golden/tiny_bpe and compare the drop-in CLI's chains with the captured ones.
 
+The corpus encoder (scripts/encode_corpus.py) is executed the same way (`run_reference_encode_corpus`: its EmDataset, em_collate,
+RobertaCtxEncoder and np.save on the toy corpus; the `id2doc.json` it wrote and a sample of the rows of its `.npy` are kept).
 The FEVER variant (scripts/eval/eval_mhop_fever.py, SURVEY.md section 8(f) rank 4) is executed the same way (`run_reference_fever`: its own code object, the same stubs;
 its final write to a directory on its author's machine fails here as it does everywhere else, after `retrieval_outputs` has been filled).
 
@@ -123,6 +125,9 @@ def build_assets(out_dir):
     raw = os.path.join(out_dir, "qas.json")
     with open(raw, "w") as f:
         f.write("\n".join(json.dumps(q) for q in qs))
+    corpus_jsonl = os.path.join(out_dir, "corpus.jsonl")
+    with open(corpus_jsonl, "w") as f:
+        f.write("\n".join(json.dumps(dict(d, intro=True) if i % 3 == 0 else d) for i, d in enumerate(docs)))
     claims = [{"id": 1000 + i, "claim": q["question"].rstrip("?"), "label": "SUPPORTS" if i % 2 else "REFUTES"} for i, q in enumerate(qs)]
     raw_fever = os.path.join(out_dir, "claims.json")
     with open(raw_fever, "w") as f:
@@ -130,7 +135,7 @@ def build_assets(out_dir):
     raw_small = os.path.join(out_dir, "qas_small.json")
     with open(raw_small, "w") as f:
         f.write("\n".join(json.dumps(q) for q in qs[:N_Q_SMALL]))
-    return {"tok": tok, "geom": geom, "sd": sd, "model_dir": model_dir, "ckpt": ckpt, "index": index_path, "xb": xb, "id2doc": paths, "raw": raw, "raw_small": raw_small, "raw_fever": raw_fever, "claims": claims,
+    return {"tok": tok, "geom": geom, "sd": sd, "model_dir": model_dir, "ckpt": ckpt, "index": index_path, "xb": xb, "id2doc": paths, "raw": raw, "raw_small": raw_small, "raw_fever": raw_fever, "claims": claims, "corpus_jsonl": corpus_jsonl,
             "questions": qs, "docs": docs}
 
 
@@ -176,8 +181,9 @@ def faiss_stub(cap):
     return m
 
 
-class Tokenizer211:
-    """transformers 2.11's `batch_encode_plus` contract for a RoBERTa tokenizer, on the installed tokenizer's BPE (see the header)."""
+class RobertaTokenizer211:
+    """transformers 2.11's `batch_encode_plus` / `encode_plus` contract for a RoBERTa tokenizer, on the installed tokenizer's BPE (see the header). (The class
+    name carries "Roberta": EmDataset's empty-text rule looks at `tokenizer.__class__.__name__`, encode_datasets.py:88.)"""
 
     def __init__(self, tok, cap):
         self.tok, self.cap = tok, cap
@@ -186,6 +192,21 @@ class Tokenizer211:
         if text and not text[0].isspace():  # RobertaTokenizer.prepare_for_tokenization, add_prefix_space defaulting to add_special_tokens
             text = " " + text
         return list(self.tok(text, add_special_tokens=False, truncation=False)["input_ids"])
+
+    def encode_plus(self, text, text_pair=None, max_length=None, return_tensors=None):
+        """`encode_plus(title, text_pair=text, max_length=n, return_tensors="pt")` (encode_datasets.py:95): special tokens, longest-first truncation, NO padding."""
+        import torch
+        assert return_tensors == "pt" and max_length
+        bos, eos = self.tok.bos_token_id, self.tok.eos_token_id
+        ia, ib = self._bpe(text), (self._bpe(text_pair) if text_pair is not None else None)
+        over = len(ia) + (len(ib) if ib is not None else 0) + (4 if ib is not None else 2) - max_length
+        for _ in range(max(over, 0)):
+            if ib is None or len(ia) > len(ib):
+                ia = ia[:-1]
+            else:
+                ib = ib[:-1]
+        row = [bos] + ia + [eos] + ([eos] + ib + [eos] if ib is not None else [])
+        return {"input_ids": torch.tensor([row], dtype=torch.long), "attention_mask": torch.ones((1, len(row)), dtype=torch.long)}
 
     def batch_encode_plus(self, batch, max_length=None, pad_to_max_length=False, return_tensors=None):
         import torch
@@ -219,6 +240,7 @@ def stubbed(cap):
     apex = types.ModuleType("apex")
     apex.amp = types.ModuleType("apex.amp")
     apex.amp.initialize = lambda model, opt_level="O1": model
+    apex.amp.register_half_function = lambda *a, **k: None
     tq = types.ModuleType("tqdm")
     tq.tqdm = lambda it, *a, **k: it
     sys.modules.update({"faiss": faiss_stub(cap), "apex": apex, "apex.amp": apex.amp, "tqdm": tq})
@@ -227,7 +249,7 @@ def stubbed(cap):
     class AutoTokenizer211:
         @staticmethod
         def from_pretrained(name, *a, **k):
-            return Tokenizer211(real_auto.from_pretrained(name, *a, **k), cap)
+            return RobertaTokenizer211(real_auto.from_pretrained(name, *a, **k), cap)
 
     torch.nn.Module.to = lambda self, *a, **k: self
     ref_utils.move_to_cuda = lambda sample: sample
@@ -306,6 +328,29 @@ def run_reference_fever(argv):
     return ns, cap, err.getvalue()
 
 
+ENCODE_SCRIPT = os.path.join(REF, "scripts", "encode_corpus.py")
+ENCODE_MAX_C_LEN, ENCODE_BATCH = 30, 50
+ENCODE_ROWS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 49, 50, 51, 77, 99, 100, 130, 150, 199, 200, 201, 255, 256)  # embedding rows kept in the fixture (5, 77, 130, 200: empty text)
+
+
+def encode_argv(a, save):
+    return ["--do_predict", "--predict_batch_size", str(ENCODE_BATCH), "--model_name", a["model_dir"], "--predict_file", a["corpus_jsonl"], "--init_checkpoint", a["ckpt"],
+            "--embed_save_path", save, "--fp16", "--max_c_len", str(ENCODE_MAX_C_LEN), "--num_workers", "0"]
+
+
+def run_reference_encode_corpus(argv):
+    """The reference's scripts/encode_corpus.py executed as __main__ under the same stubs (no GPU here: it picks the CPU itself, :50-52; `--fp16` reaches
+    the apex stub). Returns its stdout (EmDataset's prints, `embeds.size()`)."""
+    cap = Capture()
+    out = io.StringIO()
+    with stubbed(cap), contextlib.redirect_stdout(out), contextlib.redirect_stderr(io.StringIO()):
+        import torch
+        sys.argv = [ENCODE_SCRIPT] + argv
+        torch.manual_seed(0)
+        runpy.run_path(ENCODE_SCRIPT, run_name="__main__")
+    return out.getvalue()
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="mdr_cli_golden_")
     a = build_assets(tmp)
@@ -359,6 +404,17 @@ def main():
             arrays[f"f{fi}.b{b}.D2"], arrays[f"f{fi}.b{b}.I2"] = h2["D"], h2["I"].astype(np.int32)
             n_inf += sum(int(i) in EMPTY_DOCS for i in h1["I"].ravel())
         print(f"fever case {fi}: beam {b1} x {b2} topk {topk}: {len(lines)} records, {sum(map(len, lines))} JSONL bytes, {n_inf} empty passages in hop-1 beams")
+    # ---- the corpus encoder (scripts/encode_corpus.py: EmDataset -> DataLoader(em_collate) -> RobertaCtxEncoder -> np.save + id2doc.json) ----
+    save = os.path.join(tmp, "emb")
+    stdout = run_reference_encode_corpus(encode_argv(a, save))
+    emb = np.load(save + ".npy")
+    assert emb.shape == (N_DOCS, 768) and emb.dtype == np.float32
+    meta["encode_corpus"] = {"max_c_len": ENCODE_MAX_C_LEN, "predict_batch_size": ENCODE_BATCH, "rows": list(ENCODE_ROWS), "shape": list(emb.shape),
+                             "id2doc_json": open(os.path.join(save, "id2doc.json")).read(), "embeddings_sha256": hashlib.sha256(emb.tobytes()).hexdigest(),
+                             "stdout": [ln.replace(tmp, "<assets>") for ln in stdout.split("\n") if ln and "it/s]" not in ln and not ln.startswith("\r")]}
+    arrays["encode.rows"] = emb[list(ENCODE_ROWS)]
+    arrays["encode.norms"] = np.linalg.norm(emb, axis=1).astype(np.float32)
+    print(f"encode_corpus: {emb.shape}, stdout {meta['encode_corpus']['stdout']}")
     with open(os.path.join(GOLD, "cli_ref.json"), "w") as f:
         json.dump(meta, f, indent=1, ensure_ascii=False)
     np.savez_compressed(os.path.join(GOLD, "cli_ref.npz"), **arrays)
@@ -368,3 +424,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+Tokenizer211 = RobertaTokenizer211  # (name used by the tests)

@@ -8,6 +8,7 @@ built, its log lines, its `metrics` list and the bytes of its --save-path file. 
 the captured pairs, metrics, log lines and JSONL BYTES (rounds 1-4 compared them with the builder's own restatement only).
 The restatement (oracle/mhop_oracle.py) is held to the same fixture, so the tests that still use it as a checker stand on the reference too."""
 import hashlib
+import os
 import json
 
 import numpy as np
@@ -191,3 +192,25 @@ def test_fever_host_loop_reproduces_the_reference_fever_scripts_own_run(golden, 
     assert "".join(ln + "\n" for ln in lines) == case["jsonl"]
     for needle in ("Loading data...", "Building index...", "Loading corpus...", "Corpus size 257", "Loading trained model...", "Encoding claims and searching"):
         assert needle in case["log"]
+
+
+def test_em_dataset_reproduces_the_reference_encode_corpus_scripts_id2doc_and_tokens(golden, assets, tmp_path, capsys):
+    """scripts/encode_corpus.py executed by oracle/gen_cli_golden.py (its EmDataset, em_collate, RobertaCtxEncoder, np.save on the toy corpus). CPU side of the
+    drop-in: data.EmDataset writes the SAME `id2doc.json` bytes and prints the same lines, and every item's token ids equal what the reference's EmDataset got
+    from the 2.11 `encode_plus` adapter (title NFD-normalised and stripped, empty text -> title, longest-first truncation to max_c_len, no padding)."""
+    from multihop_dense_retrieval_amd import data
+    meta = golden("cli_ref.json")["encode_corpus"]
+    tok = assets["tok"]
+    ds = data.EmDataset(tok, assets["corpus_jsonl"], 70, meta["max_c_len"], False, str(tmp_path / "emb"))
+    assert open(tmp_path / "emb" / "id2doc.json").read() == meta["id2doc_json"]
+    adapter = gen_cli_golden.RobertaTokenizer211(tok, gen_cli_golden.Capture())
+    docs = [json.loads(ln) for ln in open(assets["corpus_jsonl"])]
+    assert len(ds) == len(docs) == meta["shape"][0]
+    for i, d in enumerate(docs):
+        text = d["text"] if d["text"].strip() else d["title"]
+        want = adapter.encode_plus(data.normalize(d["title"].strip()), text_pair=text.strip(), max_length=meta["max_c_len"], return_tensors="pt")
+        got = ds[i]
+        assert torch.equal(got["input_ids"], want["input_ids"]) and torch.equal(got["attention_mask"], want["attention_mask"]), i
+    out = capsys.readouterr().out.split("\n")
+    want_lines = [ln.replace("<assets>", os.path.dirname(assets["corpus_jsonl"])) for ln in meta["stdout"][:-1]]  # (the last line is the script's print(embeds.size()))
+    assert [ln for ln in out if ln] == want_lines

@@ -8,6 +8,7 @@ oracle/gen_cli_golden.py; the assets are rebuilt here from seeds + tests/golden/
     CPU, the HIP encoder runs apex-O1-class numerics (fp16 MFMA operands), so a chain may differ where two path scores are closer than that noise:
     each question's chains are compared with the captured ones through the CAPTURED path scores."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -155,3 +156,24 @@ def test_fever_cli_chains_against_the_reference_fever_scripts_run(golden, assets
     assert list(r0.keys()) == ["id", "claim", "candidate_chains"] and len(r0["candidate_chains"]) == case["topk"] and r0["id"] == 1000
     print(f"fever case {fi} beam {case['beam1']} x {case['beam2']} topk {case['topk']}: records byte-equal {equal}/23, best chain equal {top_equal}/23")
     assert top_equal >= 21 and equal >= 19
+
+
+def test_encode_corpus_cli_against_the_reference_encode_corpus_scripts_run(golden, assets, tmp_path, capsys):
+    """The corpus-encoder drop-in on the toy corpus against what the reference's scripts/encode_corpus.py wrote (fp32 on the CPU, under library stubs): the same
+    `id2doc.json` bytes, the same shape and printed lines, and the kept rows of its `.npy` within the apex-O1-class noise of the HIP encoder."""
+    from multihop_dense_retrieval_amd import encode_corpus
+    meta, z = golden("cli_ref.json")["encode_corpus"], golden("cli_ref.npz")
+    save = str(tmp_path / "emb")
+    path = encode_corpus.main(gen_cli_golden.encode_argv(assets, save), tokenizer=assets["tok"])
+    out = capsys.readouterr().out
+    emb = np.load(path)
+    assert path == save + ".npy" and list(emb.shape) == meta["shape"] and emb.dtype == np.float32
+    assert open(os.path.join(save, "id2doc.json")).read() == meta["id2doc_json"]
+    rows, want = meta["rows"], z["encode.rows"]
+    err = np.abs(emb[rows] - want)
+    nerr = np.abs(np.linalg.norm(emb, axis=1) - z["encode.norms"])
+    cos = (emb[rows] * want).sum(1) / (np.linalg.norm(emb[rows], axis=1) * np.linalg.norm(want, axis=1))
+    print(f"encode_corpus vs the reference script's fp32 run: max |d| {err.max():.3e} mean {err.mean():.3e}; row norms max |d| {nerr.max():.3e}; min cosine {cos.min():.6f}")
+    assert err.max() <= 1.5e-2 and cos.min() >= 0.99999 and nerr.max() <= 5e-3  # measured: 4.4e-3 / 0.999999 / 5.4e-4 (2-layer toy encoder; the north star allows 1e-2 on inner products of unit-scale vectors)
+    for ln in meta["stdout"]:
+        assert ln.replace("<assets>", os.path.dirname(assets["corpus_jsonl"])) in out, ln
