@@ -768,13 +768,28 @@ mips_refine8_kernel(const char* __restrict__ Xhi, const char* __restrict__ Xlo, 
         qoff[threadIdx.x] = off;
         thr[threadIdx.x] = kb ? ord32(key_score(kb) - off) >> 16 : 0u;  // (truncation rounds the threshold DOWN: safe)
     }
+    // Round 5: FILTER first, all 256 threads one candidate each, survivors compacted into LDS; THEN the 16-lane groups re-score survivors only. Before,
+    // the groups walked the list 16 candidates at a time and an iteration took an exact re-scoring (a chain of dependent loads, ~2.5 us) whenever ONE of
+    // its 16 candidates survived the filters -- ~1 in 8 does, so nearly every iteration did: a 200-entry list cost 13 such rounds (31 us per launch in the
+    // pipelined loop's profile) where its ~25 survivors need two.
+    __shared__ unsigned short surv[kWaveCandCap];
+    __shared__ int n_surv;
+    if (threadIdx.x == 0) n_surv = 0;
     __syncthreads();
-    int kept = 0;
-    for (int c = threadIdx.x >> 4; c < n; c += 16) {
+    for (int c = threadIdx.x; c < n; c += 256) {
         const u64 e = list[c];
-        const unsigned qi = (unsigned)(e >> 48), u16 = (unsigned)(e >> 32) & 0xFFFFu, row = (unsigned)e;
+        const unsigned qi = (unsigned)(e >> 48), u16 = (unsigned)(e >> 32) & 0xFFFFu;
         if (u16 < (gmax[qi] >> 16)) continue;  // U < final max L: cannot be the best row
         if (u16 < thr[qi & 31]) continue;
+        surv[atomicAdd(&n_surv, 1)] = (unsigned short)c;  // (n <= kWaveCandCap: cannot overflow)
+    }
+    __syncthreads();
+    const int ns = n_surv;
+    int kept = 0;
+    for (int s_ = threadIdx.x >> 4; s_ < ns; s_ += 16) {
+        const u64 e = list[surv[s_]];
+        const unsigned qi = (unsigned)(e >> 48), u16 = (unsigned)(e >> 32) & 0xFFFFu, row = (unsigned)e;
+        if (u16 < thr[qi & 31]) continue;  // (raised meanwhile by this block's own re-scorings)
         const float acc = exact_dot16<false>(Xhi, Xlo, nkb, q + (size_t)qi * d, row, sub, xs);
         if (sub == 0) {
             atomicMax(best + qi, make_key(acc, row));
