@@ -99,18 +99,17 @@ def parse():
     ap.add_argument("--sequential", action="store_true",
                     help="one batch at a time (hop-1 encode, search, hop-2 encode, search as four dependent stages). Default: the "
                          "software-pipelined loop -- hop 2 of batch i beside hop 1 of batch i+1: two concurrent encoder forwards (two lanes / streams) + one fused corpus pass")
-    ap.add_argument("--loop", choices=["deep", "pipelined", "shift"], default="pipelined",
-                    help="pipelined (default): hop 2 of batch i beside hop 1 of batch i+1, then their ONE corpus pass; deep: two batches in flight -- the corpus pass "
-                         "of step i (hop 2 of batch i + hop 1 of batch i+2) on its own stream beside the encoder forwards of step i+1. Measured round 4: 14.91 k vs "
-                         "14.87 k queries/s -- both kernels fill every CU, the pass takes 1.55 instead of 1.12 ms and the encoder stage 6.58 instead of 5.54 (DESIGN.md)")
-    ap.add_argument("--hop1-group", type=int, default=1,
-                    help="pipelined loop: the side-stream hop-1 forward encodes the questions of this many future batches at once, every that-many-th step")
     ap.add_argument("--no-sequential", action="store_true", help="pipelined run: do not append the sequential sub-result")
     ap.add_argument("--no-anisotropic", action="store_true", help="do not append the anisotropic-corpus MIPS sub-result (N = 1, beam 1)")
     ap.add_argument("--aniso-m", type=float, nargs="*", default=[20.0, 200.0], help="norms m of the common component of the anisotropic sub-result")
+    ap.add_argument("--structured", nargs="*", default=["clustered", "encoder"], choices=["clustered", "encoder"],
+                    help="structured-corpus MIPS sub-results to append (N = 1, beam 1; scripts/structured_corpora.py); pass the flag with no value for none")
+    ap.add_argument("--geom-len", type=int, nargs=2, default=[8, 24],
+                    help="token lengths of the synthetic passages behind the encoder-geometry sub-result (short by default so that the default run stays within "
+                         "minutes: 5 M passages = ~15 s; profiles/r06_structured_full_length.json is the same at 20..300 tokens)")
     ap.add_argument("--dump-ids", default=None, help="rank 0 writes the last step's hop-1 / hop-2 ids and scores to this .npz (tests)")
     ap.add_argument("--no-strong", action="store_true", help="N>1, weak scaling: do not append the strong-scaling sub-result")
-    ap.add_argument("--mode", choices=["retrieval", "encode-corpus", "cli"], default="retrieval",
+    ap.add_argument("--mode", choices=["retrieval", "encode-corpus", "cli", "structured"], default="retrieval",
                     help="encode-corpus: throughput of the corpus encoder (scripts/encode_corpus.py path) on a synthetic pre-tokenised corpus; "
                          "cli: queries/s of the drop-in CLI itself (scripts/eval/eval_mhop_retrieval.py main()) on synthetic assets of the headline's size")
     ap.add_argument("--questions", type=int, default=7405, help="--mode cli: questions in the synthetic qas file (HotpotQA dev has 7405)")
@@ -118,9 +117,6 @@ def parse():
     ap.add_argument("--cli-keep", action="store_true", help="--mode cli: keep the synthetic assets (and reuse the ones a previous --cli-keep run left in --cli-dir when rows / questions match)")
     ap.add_argument("--cli-workers", type=int, default=16, help="--mode cli: the CLI's --num-workers (tokenizer worker processes; the flag's default is the reference's 10)")
     ap.add_argument("--cli-legs", default="default,device", help="--mode cli: which flag sets to run: default = the reference's flags, device = --hop2-on-device, unfused = --no-pipeline-batches")
-    ap.add_argument("--lane-cus", type=int, default=0,
-                    help="CU-partitioned encoder lanes (round 5 experiment): the side lane (next batch's hop-1 forward) gets this many CUs (multiple of 8), the hop-2 "
-                         "forward the rest; 0 = both lanes may use every CU")
     ap.add_argument("--pool", type=int, default=16,
                     help="DIFFERENT question batches the timed steps cycle through (different lengths -> different hop-1 answers -> 19-22 k hop-2 tokens per batch "
                          "on the synthetic corpus); 1 = every step re-runs one batch (rounds 1-3)")
@@ -230,6 +226,47 @@ def verify_full_size(out, lo, hi, n_total, d, device, beam, bf16_rows=False):
     return res
 
 
+def _search_case(idx, q, chunks, dup_ok=False):
+    """One k = 1 search shape on a structured corpus: ms per call (HIP events, 10 back-to-back calls after 3 warm-ups), which tier decided, the candidate counts, and
+    top-1 ids against a brute-force fp32 matmul over all rows (`chunks`: callable c -> rows of chunk c, or a list of resident chunks). An id that differs counts as agreeing
+    when the brute force scores the returned row within 2e-3 of its own maximum (exact copies and fp32-matmul noise; reported separately from the strict agreement)."""
+    nq = q.shape[0]
+    D, I = idx.search_device(q, 1)
+    torch.cuda.synchronize()
+    t = idx.telemetry(nq, 1)
+    for _ in range(3):
+        idx.search_device(q, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        idx.search_device(q, 1)
+    e1.record()
+    torch.cuda.synchronize()
+    bs = torch.full((nq,), -float("inf"), device=q.device)
+    bi = torch.full((nq,), -1, dtype=torch.int64, device=q.device)
+    got = torch.full((nq,), -float("inf"), device=q.device)  # the brute force's own score of the row the index returned
+    row0 = 0
+    n_chunks = chunks[0] if isinstance(chunks, tuple) else len(chunks)
+    for c in range(n_chunks):
+        x = chunks[1](c) if isinstance(chunks, tuple) else chunks[c]
+        sc = q @ x.T
+        s_, a_ = sc.max(1)
+        better = s_ > bs
+        bs, bi = torch.where(better, s_, bs), torch.where(better, a_ + row0, bi)
+        loc = I[:, 0] - row0
+        here = (loc >= 0) & (loc < x.shape[0])
+        if bool(here.any()):
+            got = torch.where(here, sc.gather(1, loc.clamp(0, x.shape[0] - 1)[:, None])[:, 0], got)
+        row0 += x.shape[0]
+        del x, sc
+    strict = float((I[:, 0] == bi).float().mean())
+    tie_ok = float(((I[:, 0] == bi) | ((bs - got).abs() <= 2e-3)).float().mean())
+    return {"ms_per_search": round(e0.elapsed_time(e1) / 10, 4), "kernel": idx.last_kernel(), "int8_tier_decided": bool(t["i8_tier"] and not t["i8_overflow"]),
+            "exact_fallback_ran": bool(t["fallback"]), "candidates_emitted": t["candidates"], "candidates_rescored": t["i8_refined"],
+            "top1_id_agreement_with_bruteforce": round(strict, 4), "top1_agreement_up_to_exact_ties": round(tie_ok, 4),
+            "returned_score_vs_bruteforce_maxabs": round(float((D[:, 0] - got).abs().max()), 6)}
+
+
 def anisotropic_subresult(args, device):
     """The MIPS of the headline (5M x 768, beam 1, 100 / 200 queries per call) on ANISOTROPIC rows -- m u + N(0, 1) for a fixed unit
     vector u, m = args.aniso_m (dense-retrieval embeddings share a large common component; iid rows are the easy case for any
@@ -241,13 +278,16 @@ def anisotropic_subresult(args, device):
     u = torch.randn(d, generator=g, device=device)
     u = u / u.norm()
     out = {}
+    nch = -(-N // CHUNK_ROWS)
     for m in args.aniso_m:
         idx = mdr_index.IndexFlatIP(d, device=device)
         idx.reserve(N)
-        nch = -(-N // CHUNK_ROWS)
+
+        def rows_of(c, m=m):
+            return corpus_chunk(0, c, CHUNK_ROWS, d, device)[: min(CHUNK_ROWS, N - c * CHUNK_ROWS)] + m * u
         planted = None
         for c in range(nch):
-            x = corpus_chunk(0, c, CHUNK_ROWS, d, device)[: min(CHUNK_ROWS, N - c * CHUNK_ROWS)] + m * u
+            x = rows_of(c)
             if c == 0:
                 planted = x[torch.arange(200, device=device) * 1009 % x.shape[0]].clone()
             idx.add(x)
@@ -255,31 +295,71 @@ def anisotropic_subresult(args, device):
         res = {}
         for nq in (100, 200):
             q = (planted[:nq] + 0.05 * corpus_chunk(5, nq, nq, d, device)).contiguous()
-            D, I = idx.search_device(q, 1)
-            torch.cuda.synchronize()
-            t = idx.telemetry(nq, 1)
-            for _ in range(3):
-                idx.search_device(q, 1)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                idx.search_device(q, 1)
-            e1.record()
-            torch.cuda.synchronize()
-            # brute force (fp32 matmul, all rows)
-            bs = torch.full((nq,), -float("inf"), device=device)
-            bi = torch.full((nq,), -1, dtype=torch.int64, device=device)
-            for c in range(nch):
-                x = corpus_chunk(0, c, CHUNK_ROWS, d, device)[: min(CHUNK_ROWS, N - c * CHUNK_ROWS)] + m * u
-                s_, a_ = (q @ x.T).max(1)
-                better = s_ > bs
-                bs, bi = torch.where(better, s_, bs), torch.where(better, a_ + c * CHUNK_ROWS, bi)
-                del x
-            res[f"nq{nq}"] = {"ms_per_search": round(e0.elapsed_time(e1) / 10, 4), "kernel": idx.last_kernel(), "int8_tier_decided": bool(t["i8_tier"] and not t["i8_overflow"]),
-                              "exact_fallback_ran": bool(t["fallback"]), "candidates_emitted": t["candidates"], "candidates_rescored": t["i8_refined"],
-                              "top1_id_agreement_with_bruteforce": round(float((I[:, 0] == bi).float().mean()), 4)}
+            res[f"nq{nq}"] = _search_case(idx, q, (nch, rows_of))
         out[f"m={m:g}"] = res
         del idx
+        torch.cuda.empty_cache()
+    return out
+
+
+def structured_subresult(args, device):
+    """the k = 1 search of the headline on rows SHAPED LIKE REAL EMBEDDINGS (scripts/structured_corpora.py), same telemetry as `anisotropic`:
+    (i) clustered -- 20 k centres, rows = centre + 0.3 N(0,1), 1 % exact copies; queries = a row + 0.05 noise (first half) and a new cluster member (second half);
+    (ii) encoder geometry -- rows = this repo's HIP encoder outputs (random-init roberta-base: shared LayerNorm bias, nearly collapsed rows) for args.rows synthetic
+    passages of --geom-len tokens, queries from the same encoder (near-duplicates of corpus passages + fresh sequences)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import structured_corpora as sc
+    from multihop_dense_retrieval_amd import index as mdr_index
+    N, d = args.rows, args.dim
+    nch = -(-N // CHUNK_ROWS)
+    out = {}
+
+    def stats(chunks):
+        x = chunks[0][:50_000]
+        mu = x.mean(0)
+        xc = x - mu
+        return {"mean_norm": round(float(mu.norm()), 3), "row_norm_mean": round(float(x.norm(dim=1).mean()), 3),
+                "centred_row_norm_mean": round(float(xc.norm(dim=1).mean()), 4), "column_std_min_max": [round(float(xc.std(0).min()), 5), round(float(xc.std(0).max()), 5)]}
+
+    if "clustered" in args.structured:
+        centres = sc.cluster_centres(device)
+        idx = mdr_index.IndexFlatIP(d, device=device)
+        idx.reserve(N)
+        chunks = []
+        for c in range(nch):
+            x = sc.clustered_chunk(centres, c, min(CHUNK_ROWS, N - c * CHUNK_ROWS), device)
+            idx.add(x)
+            chunks.append(x)
+        res = {"corpus": f"{N} rows: {sc.N_CENTRES} centres ~ N(0,1), row = centre + {sc.SPREAD} N(0,1), {sc.DUP_FRACTION:.0%} exact copies",
+               "queries": "first half: corpus row + 0.05 N(0,1); second half: centre + 0.3 N(0,1)", "stats": stats(chunks)}
+        for nq in (100, 200):
+            q, _ = sc.clustered_queries(centres, chunks[0], nq, device)
+            res[f"nq{nq}"] = _search_case(idx, q, chunks)
+        out["clustered"] = res
+        del idx, chunks, centres
+        torch.cuda.empty_cache()
+    if "encoder" in args.structured:
+        from multihop_dense_retrieval_amd.retriever import RobertaCtxEncoder
+        lo, hi = args.geom_len
+        model = RobertaCtxEncoder.random_init(device=device, seed=3)
+        idx = mdr_index.IndexFlatIP(d, device=device)
+        idx.reserve(N)
+        chunks = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _, x in sc.encoder_rows(model, N, lo, hi, device):
+            idx.add(x)
+            chunks.append(x.clone())
+        torch.cuda.synchronize()
+        enc_s = time.perf_counter() - t0
+        res = {"corpus": f"{N} rows = RobertaCtxEncoder (random-init roberta-base, HIP) embeddings of synthetic passages of {lo}..{hi} tokens",
+               "queries": "first half: corpus passages with three tokens changed; second half: fresh sequences; same encoder",
+               "encode_seconds": round(enc_s, 1), "stats": stats(chunks)}
+        for nq in (100, 200):
+            q = sc.encoder_queries(model, nq, lo, hi, device)
+            res[f"nq{nq}"] = _search_case(idx, q, chunks)
+        out["encoder_geometry"] = res
+        del idx, chunks, model
         torch.cuda.empty_cache()
     return out
 
@@ -532,7 +612,7 @@ def cli_mode(args):
     if world == 1 and not args.no_sequential:
         sidx, local, lo, hi, GB, planted, rows_sum = build_pipeline(args, 1, 0, device, None, False)
         pipe = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len, max_q_sp_len=args.max_q_sp_len,
-                                    use_encoder=True, planted_rows=rows_sum, pipelined=2 if args.loop == "deep" else True, pool=args.pool)
+                                    use_encoder=True, planted_rows=rows_sum, pipelined=True, pool=args.pool)
         _, el = timed_steps(pipe, args, 1, device, None)
         result["device_loop"] = {"value": round(B * args.steps / el, 2), "unit": "queries/s", "ms_per_step": round(el / args.steps * 1e3, 4),
                                  "note": "bench.py default mode (device-resident synthetic loop, software-pipelined), same box, same process"}
@@ -627,7 +707,7 @@ def self_launch(args):
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` so that N ranks exist, one per GPU.
     Under a launcher (WORLD_SIZE set) nothing happens here, and a WORLD_SIZE that disagrees with --gpus is an error, not a warning: a scaling record
     whose n_gpus is not what was asked for is void. Fewer than N visible devices is an error too (unless --share-gpu, the one-GPU debugging mode)."""
-    if args.mode == "encode-corpus":
+    if args.mode in ("encode-corpus", "structured"):
         return
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is not None:
@@ -661,6 +741,13 @@ def main():
         return encode_corpus_mode(args)
     if args.mode == "cli":
         return cli_mode(args)
+    if args.mode == "structured":  # the structured-corpus MIPS sub-results alone (profile runs: scripts/measure/r6_structured.sh)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+        torch.cuda.set_device(0)
+        print(json.dumps({"metric": "ms per k = 1 search on structured corpora", "rows": args.rows, "geom_len": args.geom_len,
+                          "structured": structured_subresult(args, torch.device("cuda", 0))}), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -692,11 +779,7 @@ def main():
     pipe = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device,
                                 max_q_len=args.max_q_len, max_q_sp_len=args.max_q_sp_len,
                                 use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank, world=world, weak=weak,
-                                pipelined=False if args.sequential else (2 if args.loop == "deep" else 3 if args.loop == "shift" else True), pool=args.pool, hop1_group=args.hop1_group)
-    if pipe.encoder is not None and args.lane_cus > 0:
-        pipe.encoder.partition_lanes(args.lane_cus)
-    if pipe.encoder is not None and args.hop1_group > 1:
-        pipe.encoder.capture_on_first_use = True  # a grouped hop-1 shape recurs only every G-th step: capture it at its first sighting (in the warm-up)
+                                pipelined=not args.sequential, pool=args.pool)
     out, elapsed = timed_steps(pipe, args, world, device, dist)
 
     # self-checks, outside the timed region: structural properties + exactness against a brute-force pass over ALL rows
@@ -728,14 +811,12 @@ def main():
                                f"{B}-question batches{' per GPU (global batch ' + str(GB) + ')' if weak else ''}, 2-hop beam={args.beam} topk={args.topk}"
                                f"{' , MIPS-only (no encoder)' if not pipe.use_encoder else ', RoBERTa-base encoder (random init)'}",
                    "rows": N, "dim": d, "batch": B, "global_batch": GB, "beam": args.beam, "topk": args.topk, "shards": world,
-                   "lane_cus": args.lane_cus, "collective_world_size": (dist.get_world_size() if dist is not None else 1), "collective_backend": (dist.get_backend() if dist is not None else None),
+                   "collective_world_size": (dist.get_world_size() if dist is not None else 1), "collective_backend": (dist.get_backend() if dist is not None else None),
                    "encoder": pipe.encoder_desc(), "index_build_s": round(build_s, 2),
-                   "loop": ("software-pipelined, two batches deep: hop 2 of batch i beside hop 1 of batch i+2 (two concurrent encoder forwards, two lanes / streams), "
-                            "their ONE fused corpus pass on a third stream beside the encoder forwards of step i+1, path ranking behind it (every batch still walks "
-                            "the full hop-1 -> hop-2 chain; see `sequential` for the unpipelined loop, `pipelined_one_deep` for round 3's)") if getattr(pipe, "deep", False)
-                           else ("software-pipelined: hop 2 of batch i beside hop 1 of batch i+1 = two concurrent encoder forwards (two lanes / streams) + one fused "
-                                 "corpus pass (every batch still walks the full hop-1 -> hop-2 chain; see `sequential` for the unpipelined loop)") if pipe.pipelined
-                           else "sequential: one batch at a time, four dependent stages"},
+                   "loop": getattr(pipe, "loop_desc", None) or (
+                       ("software-pipelined: hop 2 of batch i beside hop 1 of batch i+1 = two concurrent encoder forwards (two lanes / streams) + one fused "
+                        "corpus pass (every batch still walks the full hop-1 -> hop-2 chain; see `sequential` for the unpipelined loop)") if pipe.pipelined
+                       else "sequential: one batch at a time, four dependent stages")},
         "roofline": roofline,
         "self_check": ok,
         "stage_ms": stage,
@@ -802,19 +883,6 @@ def main():
     result["stage_share"] = {"encoder": round((stage.get("hop1_encode", 0) + stage.get("hop2_encode", 0)) / ms_per_step, 3),
                              "mips": round((stage.get("hop1_search", 0) + stage.get("hop2_search", 0)) / ms_per_step, 3)}
 
-    if getattr(pipe, "deep", False) and not args.no_sequential:
-        # round 2-3's loop (one batch deep: the corpus pass between the encoder stages) on the same index, encoder and arena: sub-result of the same line
-        mhop.SyntheticTwoHop._defer_encoder = True
-        pipe_1 = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
-                                      max_q_sp_len=args.max_q_sp_len, use_encoder=not args.no_encoder, planted_rows=rows_sum, rank=rank,
-                                      world=world, weak=weak, pipelined=True, pool=args.pool)
-        mhop.SyntheticTwoHop._defer_encoder = False
-        if pipe.use_encoder:
-            pipe_1.encoder, pipe_1.arena = pipe.encoder, pipe.arena
-        _, el_1 = timed_steps(pipe_1, args, world, device, dist)
-        result["pipelined_one_deep"] = {"value": round(GB * args.steps / el_1, 2), "unit": "queries/s", "ms_per_step": round(el_1 / args.steps * 1e3, 4),
-                                        "stage_ms": pipe_1.stage_ms(), "mips_roofline": mips_roofline(pipe_1, local, args, d)}
-        del pipe_1
     if pipe.pipelined and not args.no_sequential:
         # the same job, one batch at a time (the loop exactly as the reference writes it): sub-result of the same line
         mhop.SyntheticTwoHop._defer_encoder = True  # share the encoder and the arena of the main pipeline
@@ -854,7 +922,7 @@ def main():
             mhop.SyntheticTwoHop._defer_encoder = True
             pipe_r = mhop.SyntheticTwoHop(sidx, batch=B, beam=args.beam, topk=args.topk, dim=d, device=device, max_q_len=args.max_q_len,
                                           max_q_sp_len=args.max_q_sp_len, use_encoder=True, planted_rows=rows_sum, rank=rank, world=world, weak=weak,
-                                          pipelined=2 if pipe.deep else True, pool=args.pool)
+                                          pipelined=True, pool=args.pool)
             mhop.SyntheticTwoHop._defer_encoder = False
             pipe_r.encoder, pipe_r.arena = enc_m, pipe.arena
             out_r, el_r = timed_steps(pipe_r, args, world, device, dist)
@@ -883,6 +951,8 @@ def main():
     if (rank == 0 and world == 1 and not args.no_anisotropic and args.beam == 1 and args.storage != "bf16" and d == 768
             and not (args.no_cpu_baseline or args.no_verify or args.no_encoder)):
         result["anisotropic"] = anisotropic_subresult(args, device)
+        if args.structured:
+            result["structured"] = structured_subresult(args, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, device, gpu_index=local)
     if rank == 0:

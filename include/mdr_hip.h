@@ -204,16 +204,6 @@ int mdr_assemble_hop2(const int64_t* q_ids_dev, const int64_t* q_mask_dev, int b
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * CU-partitioned lanes (round 5). The pipelined loop runs two encoder forwards at once -- hop 2 of batch i (21 k tokens, persistent one-workgroup-per-CU
- * GEMMs) beside hop 1 of batch i+1 (2.4 k tokens, ~140 short kernels) -- where the reference runs them one after the other
- * (/root/reference/scripts/eval/eval_mhop_retrieval.py:148-150,168-171). A stream created here may only use CUs [cu_lo, cu_hi) of the device (bit i of a
- * CU mask = CU i / 8 of XCD i % 8 on MI355X: a range takes the same share of every XCD; scripts/ubench/cu_mask_probe.hip); mdr_encoder_forward sizes its
- * persistent grids for the CUs of the stream it is given. Results do not depend on the partition.
- * ---------------------------------------------------------------------------------------------- */
-int mdr_stream_create_cu_range(int device, int cu_lo, int cu_hi, void** stream_out);
-int mdr_stream_destroy(void* stream);
-
-/* ------------------------------------------------------------------------------------------------
  * Host array -> device buffer, pipelined (on-disk formats: the memory-mapped token arena and any other large host array) ==
  *   batch_q_encodes = move_to_cuda(dict(batch_q_encodes))                    /root/reference/mdr/retrieval/utils/utils.py:24-41 (`.cuda()` of a host tensor)
  * for arrays of gigabytes in PAGEABLE memory (np.load(mmap_mode="r") included): two pinned staging buffers are filled by parallel memcpy while the

@@ -56,8 +56,6 @@ _SIGNATURES = {
     "mdr_topk_merge_packed": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "mdr_assemble_hop2": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                      _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
-    "mdr_stream_create_cu_range": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p)]),
-    "mdr_stream_destroy": (_c.c_int, [_c.c_void_p]),
     "mdr_upload_host": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_void_p]),
     "mdr_encoder_create": (_c.c_int, [_c.POINTER(EncoderConfig), _c.POINTER(Tensor), _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
                                       _c.POINTER(_c.c_void_p)]),

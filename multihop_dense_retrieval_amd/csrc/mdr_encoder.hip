@@ -65,11 +65,11 @@ struct mdr_encoder {
     _Float16* wproj = nullptr;
     float *bproj = nullptr, *lnp_g = nullptr, *lnp_b = nullptr;
     float fill_hint = 0.f;  // expected (tokens / (batch * seq_len)) of the next forwards; 0 = unknown (2/3 is assumed)
-    // CUs a forward may use = the CU mask of the stream it is enqueued on (hipExtStreamCreateWithCUMask; an ordinary stream: all of them). Cached per
-    // stream: the query is made at the first (warm-up) call on a stream, never inside a graph capture of a later one.
-    std::mutex cu_mu;
-    std::map<hipStream_t, int> stream_cus;
 };
+
+#ifndef MDR_CU_LANES
+#define MDR_CU_LANES 0  // 1: measurement build with CU-partitioned lanes (include/mdr_hip_measure.h)
+#endif
 
 namespace {
 
@@ -418,6 +418,9 @@ int mdr_test_attn_stamps(unsigned long long* out_host, int max_wgs) {
 }
 #endif
 
+#if MDR_CU_LANES  // measurement builds only (include/mdr_hip_measure.h): CU-partitioned lanes, a measured negative of round 5
+static std::mutex g_cu_mu;
+static std::map<hipStream_t, int> g_stream_cus;  // CUs a stream may use, read at its first un-captured forward
 int mdr_stream_create_cu_range(int device, int cu_lo, int cu_hi, void** stream_out) {
     MDR_REQUIRE(stream_out != nullptr, "stream_out is NULL");
     DeviceGuard guard(device);
@@ -436,9 +439,14 @@ int mdr_stream_create_cu_range(int device, int cu_lo, int cu_hi, void** stream_o
 }
 
 int mdr_stream_destroy(void* stream) {
+    {
+        std::lock_guard<std::mutex> lk(g_cu_mu);
+        g_stream_cus.erase((hipStream_t)stream);
+    }
     if (stream) MDR_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return MDR_OK;
 }
+#endif
 
 int mdr_encoder_set_fill_hint(mdr_encoder* h, float fill) {
     MDR_REQUIRE(h != nullptr, "encoder handle is NULL");
@@ -480,10 +488,13 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
     // tile-shape heuristics only: the packed token count is known on the device; the host may pass what it expects
     const int Test = h->fill_hint > 0.f ? std::max(1, (int)(h->fill_hint * (float)Tcap)) : Tcap - Tcap / 3;
     int ncu = h->num_cus;
-    {  // CU-partitioned lanes (round 5): the persistent GEMMs size their grids for the CUs THIS stream may run on
-        std::lock_guard<std::mutex> lk(h->cu_mu);
-        auto it = h->stream_cus.find(st);
-        if (it != h->stream_cus.end()) ncu = it->second;
+#if MDR_CU_LANES
+    {  // CU-partitioned lanes (measurement build): the persistent GEMMs size their grids for the CUs THIS stream may run on. The mask cannot be read while the
+       // stream is capturing, so the count of the warm-up call on the same stream is remembered (erased by mdr_stream_destroy); only MASKED streams are rounded
+       // to whole XCD shares
+        std::lock_guard<std::mutex> lk(g_cu_mu);
+        auto it = g_stream_cus.find(st);
+        if (it != g_stream_cus.end()) ncu = it->second;
         else {
             uint32_t mask[32] = {0};
             int n = 0;
@@ -491,10 +502,11 @@ int mdr_encoder_forward(mdr_encoder* h, const int64_t* ids_dev, const int64_t* m
             if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone && hipExtStreamGetCUMask(st, 32, mask) == hipSuccess)
                 for (uint32_t w_ : mask) n += __builtin_popcount(w_);
             else (void)hipGetLastError();
-            if (n >= 8 && n <= h->num_cus) ncu = n / 8 * 8;
-            if (cs == hipStreamCaptureStatusNone) h->stream_cus[st] = ncu;
+            if (n >= 8 && n < h->num_cus) ncu = n / 8 * 8;
+            if (cs == hipStreamCaptureStatusNone) g_stream_cus[st] = ncu;
         }
     }
+#endif
     const long long* ids = (const long long*)ids_dev;
     const long long* mask = (const long long*)mask_dev;
 

@@ -47,7 +47,12 @@ namespace {
 #include "mdr_mips_exact.inl"
 #include "mdr_mips_screen_fp16.inl"
 #include "mdr_mips_generic.inl"
+#ifndef MDR_MIPS_GEMMK
+#define MDR_MIPS_GEMMK 0  // 1: measurement build that also holds the GEMM-structured beam > 1 main pass (mdr_mips_gemmk.inl; a measured negative of round 5)
+#endif
+#if MDR_MIPS_GEMMK
 #include "mdr_mips_gemmk.inl"
+#endif
 #include "mdr_mips_screen_i8.inl"
 #include "mdr_mips_merge.inl"
 
@@ -247,11 +252,35 @@ bool wide_pass(int nq) {
     return !off && nq > kStreamQ;
 }
 // The GEMM-structured main pass of the beam > 1 search (mdr_mips_gemmk.inl) is a MEASURED NEGATIVE of round 5 (four versions, 2.7-2.9 ms per 256-query pass at
-// 5 M rows where mips_screenk32_kernel takes 2.3-2.4; NEGATIVE_RESULTS round 5): it runs only when asked for -- test-hook variant 5 (the parity test keeps it
-// honest: same lists, same bits) or MDR_MIPS_GEMMK=1 (A/B runs).
+// 5 M rows where mips_screenk32_kernel takes 2.3-2.4; NEGATIVE_RESULTS round 5). The product library does not contain it (round 6); a -DMDR_MIPS_GEMMK=1 build does
+// and runs it for test-hook variant 5 (tests/test_mips_gpu.py keeps it honest there: same lists, same bits) or with MDR_MIPS_GEMMK=1 in the environment (A/B runs).
 bool gemmk_on(const mdr_index* h) {
+#if MDR_MIPS_GEMMK
     static const bool env_on = getenv("MDR_MIPS_GEMMK") && atoi(getenv("MDR_MIPS_GEMMK")) == 1;
     return env_on || h->variant == 5;
+#else
+    (void)h;
+    return false;
+#endif
+}
+// Query groups of a call with more than kWideQ queries on the 32-queries-per-wave kernels (round 6). A pass of those kernels costs its active waves (32 queries each;
+// idle waves skip the MFMAs) down to the HBM floor of one plane read, so the ceil(nq / 256) passes share the ceil(nq / 32) waves EVENLY instead of 256 + 256 + ... + rest:
+// nq 300 = 160 + 140 (was 256 + 44: a full pass for 44 queries), nq 800 = 224 + 192 + 192 + 192 (was 3 x 256 + 32). Every buffer the groups index (query fragments in
+// 16-query blocks, bounds, thresholds, best, outputs) is linear in the query number, so a group is just (first query, count) with the first a multiple of 32.
+// MDR_MIPS_EVEN_GROUPS=0 restores the old cut, =2 additionally sends groups of at most 128 queries to the 16-queries-per-wave kernels (both for A/B runs).
+int even_groups_mode() {
+    static const int m = getenv("MDR_MIPS_EVEN_GROUPS") ? atoi(getenv("MDR_MIPS_EVEN_GROUPS")) : 1;
+    return m;
+}
+struct QGroup { int q0, n; };
+int wide_group_count(int nq) { return (nq + kWideQ - 1) / kWideQ; }
+QGroup wide_group(int nq, int gi) {
+    if (even_groups_mode() == 0) return {gi * kWideQ, nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ};
+    const int ng = wide_group_count(nq), waves = (nq + 31) / 32;
+    const int base = waves / ng, extra = waves % ng;
+    const int w0 = gi * base + (gi < extra ? gi : extra), w1 = w0 + base + (gi < extra ? 1 : 0);
+    const int end = w1 * 32 < nq ? w1 * 32 : nq;
+    return {w0 * 32, end - w0 * 32};
 }
 bool stream_kernel_supports(const mdr_index* h, int k) { return !is_bf16(h) && h->d == 768 && k <= 128; }
 bool screen_kernel_supports(const mdr_index* h, int k) { return h->d == 768 && k <= 256; }
@@ -449,17 +478,17 @@ int run_screen32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
     u64* scand = (u64*)(ws + p.off_scand);
     int* sctl = (int*)(ws + p.off_sctl);
     int* wave_cnt = sctl + 64;
-    const int ngroups = (nq + kWideQ - 1) / kWideQ;
+    const int ngroups = wide_group_count(nq);
     const int n_sb = (int)((h->ntotal + 31) / 32);
-    const size_t qgroup_bytes = (size_t)kWideQ * h->d * 2;
     // (gmax and sctl[0..63] are part of the search call's zero block: cleared once by mdr_index_search)
     for (int gi = 0; gi < ngroups; ++gi) {
-        const int nqg = nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ;
-        const char* qg = qhi + gi * qgroup_bytes;
+        const QGroup gq = wide_group(nq, gi);
+        const int nqg = gq.n;
+        const char* qg = qhi + (size_t)gq.q0 * h->d * 2;
         hipLaunchKernelGGL((mips_screen32_kernel<NKB, 0, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
-                           (const float*)(bound + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, sctl, run_if);
+                           (const float*)(bound + (size_t)gq.q0), nqg, gq.q0, gmax + (size_t)gq.q0, scand, wave_cnt, sctl, run_if);
         hipLaunchKernelGGL((mips_screen32_kernel<NKB, 1, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
-                           (const float*)(bound + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, sctl, run_if);
+                           (const float*)(bound + (size_t)gq.q0), nqg, gq.q0, gmax + (size_t)gq.q0, scand, wave_cnt, sctl, run_if);
         hipLaunchKernelGGL((mips_refine_kernel<BF>), dim3(p.G * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev,
                            (const u64*)scand, (const int*)wave_cnt, best, row_unscale(h), run_if);
         MDR_HIP_TRY(hipGetLastError());
@@ -480,26 +509,25 @@ int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
     int* ctl8 = (int*)(ws + p.off_ctl8);
     char* q8 = ws + p.off_q8;
     f32x4* qab = (f32x4*)(ws + p.off_qab);
-    const int ngroups = (nq + kWideQ - 1) / kWideQ;
-    const int nq_pad = ngroups * kWideQ;
+    const int ngroups = wide_group_count(nq);
     const int n_sb = (int)((h->ntotal + 31) / 32);
     u64* gstar = (u64*)(ws + p.off_gstar);
     // (gmax, gstar and ctl8 are part of the search call's zero block: cleared once by mdr_index_search)
     // (q8 / qab were written by prep_queries_both_kernel, together with the fp16 fragments: mdr_index_search)
     for (int gi = 0; gi < ngroups; ++gi) {
-        const int nqg = nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ;
-        const char* qg = q8 + (size_t)gi * kWideQ * h->d;
+        const QGroup gq = wide_group(nq, gi);
+        const int nqg = gq.n;
+        const size_t g0 = (size_t)gq.q0;
+        const char* qg = q8 + g0 * h->d;
         if (gi) MDR_HIP_TRY(hipMemsetAsync(ctl8 + 3, 0, sizeof(int), st));  // emitted-candidate total of this group's pass
         hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 0, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
-                           (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8, gstar + (size_t)gi * kWideQ,
-                           (const u64*)best);
+                           (const f32x4*)(qab + g0), nqg, gq.q0, gmax + g0, scand, wave_cnt, ctl8, gstar + g0, (const u64*)best);
         hipLaunchKernelGGL(mips_star8_kernel, dim3((nqg + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb,
-                           q_dev + (size_t)gi * kWideQ * h->d, (const u64*)(gstar + (size_t)gi * kWideQ), nqg, best + (size_t)gi * kWideQ, row_unscale(h));
+                           q_dev + g0 * h->d, (const u64*)(gstar + g0), nqg, best + g0, row_unscale(h));
         hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 1, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
-                           (const f32x4*)(qab + (size_t)gi * kWideQ), nqg, gi * kWideQ, gmax + (size_t)gi * kWideQ, scand, wave_cnt, ctl8, gstar + (size_t)gi * kWideQ,
-                           (const u64*)best);
+                           (const f32x4*)(qab + g0), nqg, gq.q0, gmax + g0, scand, wave_cnt, ctl8, gstar + g0, (const u64*)best);
         hipLaunchKernelGGL(mips_star8_kernel, dim3((nqg + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb,
-                           q_dev + (size_t)gi * kWideQ * h->d, (const u64*)(gstar + (size_t)gi * kWideQ), nqg, best + (size_t)gi * kWideQ, row_unscale(h));
+                           q_dev + g0 * h->d, (const u64*)(gstar + g0), nqg, best + g0, row_unscale(h));
         hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8w * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
                            (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nqg, (const f32x4*)qab, row_unscale(h));
         MDR_HIP_TRY(hipGetLastError());
@@ -562,8 +590,10 @@ int run_screenk32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_de
     const size_t merge_lds = (size_t)kMergeKLds * 8;
     int rc_ = ensure_dynamic_lds((const void*)mips_screen32_kernel<NKB, 2, BF>, (int)lds_bytes);
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screenk32_kernel<NKB, BF>, (int)lds_bytes);
+#if MDR_MIPS_GEMMK
     constexpr size_t gemmk_lds = (4 + 4) * 16 * kFragBytes + kWideQ * 8;  // four row-fragment + four query-fragment slots of 16 KiB, list counters, thresholds
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_gemmk_kernel<BF>, (int)gemmk_lds);
+#endif
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen_kernel<NKB, 2, BF>, (int)lds_bytes);
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screenk_kernel<NKB, BF>, (int)lds_bytes);
     if (!rc_) rc_ = ensure_dynamic_lds((const void*)merge_screenk_kernel<BF>, (int)merge_lds);
@@ -574,40 +604,45 @@ int run_screenk32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_de
     int* sctl = (int*)(ws + p.off_sctl);
     u64* cand = (u64*)(ws + p.off_cand);
     int* cnt = (int*)(ws + p.off_cnt);
-    const int ngroups = (nq + kWideQ - 1) / kWideQ;
+    const int ngroups = wide_group_count(nq);
     const int n_sb = (int)((h->ntotal + 31) / 32);
     const int stages = sample_stages_for(k);
-    const size_t qgroup_bytes = (size_t)kWideQ * h->d * 2;
     MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
     for (int gi = 0; gi < ngroups; ++gi) {
-        const int nqg = nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ;
-        const char* qg = qhi + gi * qgroup_bytes;
-        const float* bg = bound + (size_t)gi * kWideQ;
-        float* tg = tau0 + (size_t)gi * kWideQ;
-        const bool narrow = ngroups > 1 && gi == ngroups - 1 && nqg <= kStreamQ;  // the remainder group: 16 queries per wave, list stride kStreamQ
+        const QGroup gq = wide_group(nq, gi);
+        const int nqg = gq.n;
+        const size_t g0 = (size_t)gq.q0;
+        const char* qg = qhi + g0 * h->d * 2;
+        const float* bg = bound + g0;
+        float* tg = tau0 + g0;
+        // a group of at most 128 queries may take the 16-queries-per-wave kernels (list stride kStreamQ): always under the old cut (its remainder group), under the even
+        // cut only when asked for (mode 2) -- an even group is at least half a pass's waves, which the 32-queries-per-wave kernel serves at its HBM floor
+        const bool narrow = ngroups > 1 && nqg <= kStreamQ && (even_groups_mode() == 2 || (even_groups_mode() == 0 && gi == ngroups - 1));
         const int qcap = narrow ? kStreamQ : kWideQ;
         MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * qcap * 4, st));
         MDR_HIP_TRY(hipMemsetAsync(wgmax, 0, (size_t)p.G * stages * qcap * 4, st));
         if (narrow) {
             hipLaunchKernelGGL((mips_screen_kernel<NKB, 2, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg, nqg,
-                               gi * kWideQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, stages);
+                               gq.q0, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, stages);
             hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G * stages, k, tg, qcap);
             hipLaunchKernelGGL((mips_screenk_kernel<NKB, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg,
                                (const float*)tg, nqg, cand, cnt, k, sctl);
         } else {
             hipLaunchKernelGGL((mips_screen32_kernel<NKB, 2, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg, nqg,
-                               gi * kWideQ, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, stages);
+                               gq.q0, wgmax, (u64*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, stages);
             hipLaunchKernelGGL(kth_of_maxima_kernel, dim3(nqg), dim3(256), 0, st, (const unsigned*)wgmax, p.G * stages, k, tg, qcap);
-            if (gemmk_on(h) && h->ntotal >= 256ll * p.G)  // round 5 (not the default: see gemmk_on): the main pass as a 256 x 256 x 64 GEMM with the screen as its epilogue (mdr_mips_gemmk.inl)
+#if MDR_MIPS_GEMMK
+            if (gemmk_on(h) && h->ntotal >= 256ll * p.G)  // measurement build: the main pass as a 256 x 256 x 64 GEMM with the screen as its epilogue (mdr_mips_gemmk.inl)
                 hipLaunchKernelGGL((mips_gemmk_kernel<BF>), dim3(p.G), dim3(512), gemmk_lds, st, (const char*)h->hi, (long long)h->ntotal, qg, bg, (const float*)tg, nqg,
                                    cand, cnt, sctl);
             else
+#endif
                 hipLaunchKernelGGL((mips_screenk32_kernel<NKB, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg, bg,
                                    (const float*)tg, nqg, cand, cnt, k, sctl);
         }
         hipLaunchKernelGGL((merge_screenk_kernel<BF>), dim3(nqg), dim3(256), merge_lds, st, (const u64*)cand, (const int*)cnt, p.G, k, bg, (const char*)h->hi,
-                           (const char*)h->lo, h->nkb, q_dev + (size_t)gi * kWideQ * h->d, D_dev + (size_t)gi * kWideQ * k,
-                           I_dev + (size_t)gi * kWideQ * k, id_offset, sctl, qcap, row_unscale(h));
+                           (const char*)h->lo, h->nkb, q_dev + g0 * h->d, D_dev + g0 * k,
+                           I_dev + g0 * k, id_offset, sctl, qcap, row_unscale(h));
         MDR_HIP_TRY(hipGetLastError());
     }
     return MDR_OK;
@@ -698,16 +733,28 @@ void parallel_copy(char* dst, const char* src, size_t bytes, int nt) {
 // so chunk c + 1 is read from the host and crosses PCIe while chunk c is converted; a slot is refilled when its "converted" event has completed.
 // Returns an error code (the caller rolls the index back); `n` rows starting at logical row h->ntotal.
 int upload_host_rows(mdr_index* h, const char* rows, long long n, int src_dtype, size_t row_src, hipStream_t st) {
-    const size_t chunk_bytes_target = 96ull << 20;
-    const long long chunk_rows = (long long)(chunk_bytes_target / row_src) > 0 ? (long long)(chunk_bytes_target / row_src) : 1;
+    // Slots are sized by the call (a 100-row add used to allocate 2 x 96 MiB of device staging + 2 x 96 MiB of pinned host memory and start a thread):
+    // chunk = min(n, 96 MiB / row) rows, and an add that fits ONE small chunk takes the plain road -- one hipMemcpyAsync out of the caller's (pageable) rows into a
+    // staging buffer of exactly that size, the conversion, a sync; no pinned memory, no producer thread.
+    const size_t chunk_bytes_target = 96ull << 20, plain_bytes_max = 16ull << 20;
+    long long chunk_rows = (long long)(chunk_bytes_target / row_src) > 0 ? (long long)(chunk_bytes_target / row_src) : 1;
+    if (n < chunk_rows) chunk_rows = n;
     const size_t chunk_bytes = (size_t)chunk_rows * row_src;
     const long long nchunks = (n + chunk_rows - 1) / chunk_rows;
-    if (2 * chunk_bytes > h->stage_bytes) {
+    const bool plain = nchunks == 1 && chunk_bytes <= plain_bytes_max;
+    const size_t stage_need = plain ? chunk_bytes : 2 * chunk_bytes;
+    if (stage_need > h->stage_bytes) {
         if (h->stage) MDR_HIP_TRY(hipFree(h->stage));
         h->stage = nullptr;
         h->stage_bytes = 0;
-        MDR_HIP_TRY(hipMalloc(&h->stage, 2 * chunk_bytes));
-        h->stage_bytes = 2 * chunk_bytes;
+        MDR_HIP_TRY(hipMalloc(&h->stage, stage_need));
+        h->stage_bytes = stage_need;
+    }
+    if (plain) {
+        MDR_HIP_TRY(hipMemcpyAsync(h->stage, rows, chunk_bytes, hipMemcpyHostToDevice, st));
+        int rc_p = add_any(h, h->stage, src_dtype, n, h->ntotal, st);
+        if (rc_p == MDR_OK && hipStreamSynchronize(st) != hipSuccess) rc_p = set_error(MDR_E_HIP, "stream sync failed in add()");
+        return rc_p;
     }
     if (chunk_bytes > h->pin_bytes) {
         for (int i = 0; i < 2; ++i) {
@@ -890,8 +937,8 @@ int64_t mdr_index_stream_bytes(const mdr_index* h) { return h ? (int64_t)((h->nt
 
 int mdr_index_set_variant(mdr_index* h, int variant) {
     MDR_REQUIRE(h != nullptr, "index handle is NULL");
-    MDR_REQUIRE(variant >= 0 && variant <= 5, "variant must be 0 (auto), 1 (generic), 2 (exact stream), 3 (screen + refine), 4 (screen + refine without the int8 tier) or "
-                                              "5 (screen path with the GEMM-structured screen-k pass for groups of 256 queries: a measured negative kept for its parity test)");
+    MDR_REQUIRE(variant >= 0 && variant <= (MDR_MIPS_GEMMK ? 5 : 4), "variant must be 0 (auto), 1 (generic), 2 (exact stream), 3 (screen + refine) or 4 (screen + refine "
+                                                                      "without the int8 tier); 5 (GEMM-structured screen-k pass) exists in -DMDR_MIPS_GEMMK=1 builds only");
     h->variant = variant;
     return MDR_OK;
 }

@@ -68,9 +68,6 @@ def expected_state_dict_shapes(config, with_pooler=True):
     return sd
 
 
-_CU_RANGE_STREAMS = {}  # (device, cu_lo, cu_hi) -> (torch.cuda.ExternalStream, raw pointer); process lifetime (see partition_lanes)
-
-
 class _Lane:
     def __init__(self):
         self.ws = None
@@ -155,39 +152,27 @@ class _HipRobertaEncoder:
             st = self._lanes[lane] = _Lane()
         return st
 
-    def partition_lanes(self, side_cus):
-        """CU-partitioned lanes (round 5): lane 1 (the short forward of the pipelined loop) gets the last `side_cus` CUs of the device, lane 0 the rest; each
-        lane's forwards run on its own CU-masked stream (mdr_stream_create_cu_range) whatever stream the caller is on (events order them with the caller's
-        stream). side_cus = 0 removes the partition. Captured graphs are dropped: a capture freezes grid sizes."""
-        # (the masked streams are never destroyed: torch's caching allocator keeps per-stream state for every stream a tensor was allocated on, and a
-        #  graph's private pool outlives the capture -- a destroyed stream under either is a crash at some later free. They are cached per CU range.)
-        self._lane_streams = {}
+    def bind_lane_stream(self, lane, stream):
+        """Bind a lane to a stream of its own: the lane's forwards then run (and are captured) on that stream whatever stream the caller is on, ordered with the
+        caller's stream by events. None removes the binding. Captured graphs of every lane are dropped (a capture freezes the stream it was made on)."""
+        if not hasattr(self, "_lane_streams"):
+            self._lane_streams = {}
         for st in self._lanes.values():
             st.graphs.clear()
-        side_cus = int(side_cus)
-        if side_cus <= 0:
-            return
-        n = torch.cuda.get_device_properties(self.device).multi_processor_count
-        if side_cus % 8 or not 8 <= side_cus <= n - 8:
-            raise ValueError(f"side_cus must be a multiple of 8 in [8, {n - 8}]")
-        for lane, (lo, hi) in ((0, (0, n - side_cus)), (1, (n - side_cus, n))):
-            key = (self.device.index or 0, lo, hi)
-            if key not in _CU_RANGE_STREAMS:
-                ptr = ctypes.c_void_p()
-                _lib.check(_lib.lib().mdr_stream_create_cu_range(key[0], lo, hi, ctypes.byref(ptr)))
-                _CU_RANGE_STREAMS[key] = (torch.cuda.ExternalStream(ptr.value, device=self.device), ptr.value)
-            self._lane_streams[lane] = _CU_RANGE_STREAMS[key]
+        if stream is None:
+            self._lane_streams.pop(lane, None)
+        else:
+            self._lane_streams[lane] = stream
 
     def lane_stream(self, lane):
-        s_ = getattr(self, "_lane_streams", {}).get(lane)
-        return None if s_ is None else s_[0]
+        return getattr(self, "_lane_streams", {}).get(lane)
 
     def encode_seq(self, input_ids, mask, lane=0):
         """lane: which workspace / graph cache this call uses. Calls on DIFFERENT lanes may overlap on different streams (the
         pipelined retrieval loop encodes the next batch's questions beside the current batch's hop-2 inputs)."""
         ls = self.lane_stream(lane)
         if ls is not None and torch.cuda.current_stream(self.device) != ls:
-            # this lane owns a CU-masked stream: run there, ordered behind what the caller's stream holds, and let the caller's stream wait for the result
+            # this lane is bound to its own stream: run there, ordered behind what the caller's stream holds, and let the caller's stream wait for the result
             cur = torch.cuda.current_stream(self.device)
             ev = torch.cuda.Event()
             ev.record(cur)
@@ -271,7 +256,7 @@ class _HipRobertaEncoder:
                 self._forward_into(sid, smk, sout, lane)  # warm-up: sizes the workspace, sets kernel attributes
                 torch.cuda.synchronize(self.device)
                 graph = torch.cuda.CUDAGraph()
-                ls = self.lane_stream(lane)  # a CU-masked lane stream: capture ON it (the library sizes its grids by the capturing stream's CUs)
+                ls = self.lane_stream(lane)  # a lane bound to its own stream is captured ON it
                 with (torch.cuda.graph(graph, stream=ls) if ls is not None else torch.cuda.graph(graph)):
                     self._forward_into(sid, smk, sout, lane)
             finally:

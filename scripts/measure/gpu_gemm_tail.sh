@@ -6,7 +6,7 @@ timeout 900 python -m pytest tests/test_gemm_gpu.py tests/test_encoder_gpu.py -m
 echo "== GEMM time over M (kernel 0 = the forward's choice)"
 timeout 300 python scripts/measure/gpu_gemm_msweep.py 2>&1 | tail -30
 echo "== bench (pipelined loop, pool 16)"
-timeout 900 python bench.py --loop pipelined --no-cpu-baseline --no-anisotropic > $OUT/bench.json 2> $OUT/bench.err; tail -2 $OUT/bench.err
+timeout 900 python bench.py --no-cpu-baseline --no-anisotropic > $OUT/bench.json 2> $OUT/bench.err; tail -2 $OUT/bench.err
 python - $OUT/bench.json <<'PY'
 import json, sys
 try:

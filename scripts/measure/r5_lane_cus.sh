@@ -1,11 +1,11 @@
 #!/bin/bash
 # round 5: CU-partitioned encoder lanes in the headline loop -- the side lane (hop-1 forward of the next batch) on its own CUs, the hop-2 forward on the rest
-# (mdr_stream_create_cu_range; bench.py --lane-cus N). Alternating runs on ONE box -> gpurun_out/<tag>/lanes.txt
+# (mdr_stream_create_cu_range; scripts/measure/bench_loops.py --lane-cus N with a -DMDR_CU_LANES=1 build via MDR_LIB_PATH). Alternating runs on ONE box -> gpurun_out/<tag>/lanes.txt
 set -u
 TAG=${1:-r5lanes}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 for rep in 1 2; do
   for N in 0 16 32 48 64; do
-    timeout 300 python bench.py --lane-cus $N --no-cpu-baseline --no-anisotropic --no-sequential > $OUT/b_${N}_$rep.json 2> $OUT/b_${N}_$rep.err || tail -3 $OUT/b_${N}_$rep.err
+    timeout 300 python scripts/measure/bench_loops.py --lane-cus $N --no-cpu-baseline --no-anisotropic --no-sequential > $OUT/b_${N}_$rep.json 2> $OUT/b_${N}_$rep.err || tail -3 $OUT/b_${N}_$rep.err
     python - $OUT/b_${N}_$rep.json $N <<'PY' | tee -a $OUT/lanes.txt
 import json, sys
 try:

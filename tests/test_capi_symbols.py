@@ -42,13 +42,16 @@ def test_product_library_holds_no_measurement_code():
     lib = ctypes.CDLL(path)
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mdr_hip_measure.h")).read(), flags=re.S)
     hooks = sorted(set(re.findall(r"\b(mdr_[a-z0-9_]+)\s*\(", text)))
-    assert hooks == ["mdr_test_attn_stamps", "mdr_test_gemm_stamps", "mdr_test_i8_stamps"]
+    assert hooks == ["mdr_stream_create_cu_range", "mdr_stream_destroy", "mdr_test_attn_stamps", "mdr_test_gemm_stamps", "mdr_test_i8_stamps"]
     for name in hooks:
         assert not hasattr(lib, name), f"{name} is a measurement hook but the product library exports it"
+    assert len([n for n in declared_symbols()]) == 27  # round 6: the CU-lane pair moved to the measurement header
     blob = open(path, "rb").read()
-    for knob in (b"MDR_GEMM_ABL", b"MDR_GEMM_EPI", b"MDR_I8_ABL", b"MDR_ATTN_ABL", b"g_gemm_stamp", b"g_i8_stamp", b"g_attn_stamp"):
+    for knob in (b"MDR_GEMM_ABL", b"MDR_GEMM_EPI", b"MDR_I8_ABL", b"MDR_ATTN_ABL", b"g_gemm_stamp", b"g_i8_stamp", b"g_attn_stamp", b"g_stream_cus", b"mips_gemmk_kernel"):
         assert knob not in blob, f"{knob!r} found in the product library"
-    allowed = {"MDR_GEMM_CFG", "MDR_MIPS_WIDE", "MDR_MIPS_I8", "MDR_MIPS_GEMMK", "MDR_UPLOAD_THREADS"}  # (the last: memcpy threads of the host-upload pipeline)
+    # (MDR_UPLOAD_THREADS: memcpy threads of the host-upload pipeline; MDR_MIPS_EVEN_GROUPS: how the passes of a > 256-query call share the queries;
+    #  MDR_MIPS_GEMMK is read by -DMDR_MIPS_GEMMK=1 measurement builds only)
+    allowed = {"MDR_GEMM_CFG", "MDR_MIPS_WIDE", "MDR_MIPS_I8", "MDR_MIPS_GEMMK", "MDR_UPLOAD_THREADS", "MDR_MIPS_EVEN_GROUPS"}
     seen = set()
     for src in glob.glob(os.path.join(ROOT, "multihop_dense_retrieval_amd", "csrc", "*")):
         seen |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(src).read()))

@@ -433,3 +433,58 @@ def test_config4_shard_shape_6_25m_bf16_rows_800_queries_k100(mdr):
     assert float((bs[:, k - 1] - D[sample][:, k - 1]).max()) <= 2e-3  # nothing anywhere beats the returned k-th
     differ = bi != I[sample]
     assert bool(((bs - D[sample]).abs()[differ] <= 2e-3).all()) and float(differ.float().mean()) <= 0.05
+
+
+@pytest.mark.parametrize("nq", [100, 200])
+def test_five_million_clustered_rows_with_exact_copies(mdr, nq):
+    """the k = 1 search on rows shaped like real embeddings (scripts/structured_corpora.py: 20 k clusters of ~250 rows at 0.3 sigma, 1 % exact
+    copies), at the headline's 5 M rows. Properties: a planted query returns its row or that row's exact copy; every returned score is the fp64 product with the
+    returned row (1e-3); no row anywhere beats it (brute force over all 20 chunks, fp32-matmul noise 2e-3); where the id differs from the brute force's the two
+    rows score the same. k = 4 on the same index: sorted, distinct, the same bars."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import structured_corpora as sc
+    dev = torch.device("cuda")
+    centres = sc.cluster_centres(dev)
+    idx = mdr.IndexFlatIP(D_)
+    idx.reserve(20 * CHUNK)
+    chunks = []
+    for c in range(20):
+        x = sc.clustered_chunk(centres, c, CHUNK, dev)
+        idx.add(x)
+        chunks.append(x)
+    q, planted = sc.clustered_queries(centres, chunks[0], nq, dev)
+
+    def brute(k):
+        run_s = torch.full((nq, k), -float("inf"), device=dev)
+        run_i = torch.full((nq, k), -1, dtype=torch.int64, device=dev)
+        for c, x in enumerate(chunks):
+            s, i = torch.topk(q @ x.T, k, dim=1)
+            cat_s, cat_i = torch.cat([run_s, s], 1), torch.cat([run_i, i + c * CHUNK], 1)
+            run_s, o = torch.topk(cat_s, k, dim=1)
+            run_i = torch.gather(cat_i, 1, o)
+        return run_s, run_i
+
+    def exact(I):
+        rows = torch.stack([chunks[int(i) // CHUNK][int(i) % CHUNK] for i in I.flatten().tolist()]).view(I.shape + (D_,))
+        return (rows.double() * q[:, None, :].double()).sum(-1)
+
+    for k in (1, 4):
+        D, I = idx.search_device(q, k)
+        t = idx.telemetry(nq, k)
+        print(f"clustered 5 M rows nq {nq} k {k}: kernel {idx.last_kernel()} telemetry {t}")
+        assert t["path"] == 3 and t["fallback"] == 0, t
+        ex = exact(I)
+        assert float((ex - D.double()).abs().max()) <= 1e-3
+        assert bool((D[:, :-1] >= D[:, 1:]).all()) and bool((I >= 0).all())
+        assert bool((I.sort(1).values[:, 1:] != I.sort(1).values[:, :-1]).all())
+        half = nq // 2
+        same_row = I[:half, 0] == planted
+        # a planted row may have an exact copy (1 % of the rows): then the lower id of the two wins -- same score to the bit
+        p_ex = (chunks[0][planted].double() * q[:half].double()).sum(1)
+        assert bool((same_row | ((ex[:half, 0] - p_ex).abs() == 0)).all())
+        bs, bi = brute(k)
+        assert float((bs[:, k - 1] - D[:, k - 1]).max()) <= 2e-3
+        differ = bi != I
+        assert bool(((bs - D).abs()[differ] <= 2e-3).all())
