@@ -62,9 +62,15 @@ from oracle import seeded  # noqa: E402
 N_DOCS, N_Q, SEED = 257, 23, 41
 MAX_Q_LEN, MAX_Q_SP_LEN, BATCH = 12, 40, 10
 EMPTY_DOCS = (5, 77, 130, 200)
-DUPLICATE_ROWS = ((100, 73), (201, 175))  # xb[100] = xb[73], xb[201] = xb[175] (rows a few questions retrieve): equal hop scores -> equal path scores
+DUPLICATE_ROWS = ((100, 73), (201, 175), (150, 107), (151, 213))  # xb[100] = xb[73], xb[201] = xb[175] (rows a few questions retrieve): equal hop scores -> equal path scores
 # supporting titles by question number mod 4: chosen among the passages the toy encoder retrieves most, so that every metric takes both values
-SP_BY_RESIDUE = (["T173", "T58"], ["T173", "T213"], ["T58", "T-absent"], None)
+SP_BY_RESIDUE = (["T173", "T58"], ["T173", "Zürich"], ["T58", "T-absent"], None)  # "Zürich" = passage 213's title (precomposed u-umlaut)
+# round 6: strings no fixture carried before. Titles with precomposed / combining / padded characters (EmDataset NFD-normalises and strips the title
+# it tokenises, encode_datasets.py:95, and writes the RAW title to id2doc.json, :76-78); passage texts holding the tokenizer's own special-token strings; a question that
+# ends in " ?" (one "?" is stripped, :139: the trailing blank stays) and one with leading blanks.
+TITLE_OVERRIDES = {213: "Zürich", 214: "Krako\u0301w", 215: "  Kraków  ", 216: "Ångström (unit)"}
+TEXT_SUFFIXES = {58: " <s> inner </s> <mask> tail", 173: " so <mask> it </s>", 12: " <s>"}
+Q_TRAILING_BLANK, Q_LEADING_BLANKS = 5, 6
 # (beam, topk, corpus-dict shape, extra flags).  (50, 50): the reference's own downstream setting (README.md:240-241 b50_k50), JSONL kept as a hash.
 # (100, 100): README.md:241 b100_k100, on the first N_Q_SMALL questions only (a 100 x 100 beam grid per question: the capture stays small).
 CASES = [(1, 1, "list", []), (3, 4, "list", []), (5, 2, "dict", []), (3, 4, "dict", ["--only-eval-ans"]), (50, 50, "list", []), (100, 100, "dict", ["small"])]
@@ -104,6 +110,10 @@ def build_assets(out_dir):
     for i in EMPTY_DOCS:
         docs[i]["text"] = "" if i % 2 else "  \t"
     docs[9]["title"] = "T8"  # two passages under one title: the metrics work on titles (:219-242)
+    for i, t in TITLE_OVERRIDES.items():
+        docs[i]["title"] = t
+    for i, suf in TEXT_SUFFIXES.items():
+        docs[i]["text"] += suf
     xb = seeded.normal(SEED, "cli.xb", (N_DOCS, 768))
     for dst, src in DUPLICATE_ROWS:
         xb[dst] = xb[src]
@@ -118,7 +128,9 @@ def build_assets(out_dir):
     for i in range(N_Q):
         r = N_DOCS + i
         text = " ".join(words[j] for j in pick[r, :4 + lens[r] % 9])
-        q = text + ("??" if i == 3 else "" if i == 4 else "?")
+        q = text + ("??" if i == 3 else "" if i == 4 else " ?" if i == Q_TRAILING_BLANK else "?")
+        if i == Q_LEADING_BLANKS:
+            q = "  " + q
         ans = ["yes"] if i % 5 == 0 else ["no"] if i == 7 else [(docs[(i * 7) % N_DOCS]["text"].split() or ["Seine"])[0] if i % 2 else "zzz-not-there", "not in any passage"]
         qs.append({"_id": f"q{i}", "question": q, "answer": ans, "sp": SP_BY_RESIDUE[i % 4] or [f"T{(i * 11) % N_DOCS}", f"T{(i * 11 + 1) % N_DOCS}"],
                    "type": "bridge" if i % 3 else "comparison"})
@@ -128,6 +140,21 @@ def build_assets(out_dir):
     corpus_jsonl = os.path.join(out_dir, "corpus.jsonl")
     with open(corpus_jsonl, "w") as f:
         f.write("\n".join(json.dumps(dict(d, intro=True) if i % 3 == 0 else d) for i, d in enumerate(docs)))
+    # the other corpus formats EmDataset reads (encode_datasets.py:56-72): a TSV with the `id<TAB>text<TAB>title` header row, and a JSONL whose PATH contains "fever"
+    import csv
+    corpus_tsv = os.path.join(out_dir, "corpus.tsv")
+    with open(corpus_tsv, "w", newline="") as f:
+        w = csv.writer(f, delimiter="\t")
+        w.writerow(["id", "text", "title"])
+        for i, d in enumerate(docs):
+            w.writerow([str(i), d["text"], d["title"]])
+    corpus_fever = os.path.join(out_dir, "fever_corpus.jsonl")
+    with open(corpus_fever, "w") as f:
+        f.write(open(corpus_jsonl).read())
+    # --is_query_embed (encode_datasets.py:52-54,82): a JSONL of records that still need "title" and "text" (its __getitem__ reads both), cut at --max_q_len, no id2doc.json
+    queries_embed = os.path.join(out_dir, "queries_embed.jsonl")
+    with open(queries_embed, "w") as f:
+        f.write("\n".join(json.dumps({"title": d["title"], "text": d["text"], "question": q["question"]}) for d, q in zip(docs[200:200 + N_Q], qs)))
     claims = [{"id": 1000 + i, "claim": q["question"].rstrip("?"), "label": "SUPPORTS" if i % 2 else "REFUTES"} for i, q in enumerate(qs)]
     raw_fever = os.path.join(out_dir, "claims.json")
     with open(raw_fever, "w") as f:
@@ -136,7 +163,7 @@ def build_assets(out_dir):
     with open(raw_small, "w") as f:
         f.write("\n".join(json.dumps(q) for q in qs[:N_Q_SMALL]))
     return {"tok": tok, "geom": geom, "sd": sd, "model_dir": model_dir, "ckpt": ckpt, "index": index_path, "xb": xb, "id2doc": paths, "raw": raw, "raw_small": raw_small, "raw_fever": raw_fever, "claims": claims, "corpus_jsonl": corpus_jsonl,
-            "questions": qs, "docs": docs}
+            "corpus_tsv": corpus_tsv, "corpus_fever": corpus_fever, "queries_embed": queries_embed, "questions": qs, "docs": docs}
 
 
 def cli_argv(a, beam, topk, shape, extra, save):
@@ -152,7 +179,7 @@ def cli_argv(a, beam, topk, shape, extra, save):
 # --------------------------------------------------------------------------------------------------------------------------------------
 class Capture:
     def __init__(self):
-        self.searches, self.tokenizer_calls = [], []
+        self.searches, self.tokenizer_calls, self.encode_plus_calls = [], [], []
 
 
 def faiss_stub(cap):
@@ -197,6 +224,7 @@ class RobertaTokenizer211:
         """`encode_plus(title, text_pair=text, max_length=n, return_tensors="pt")` (encode_datasets.py:95): special tokens, longest-first truncation, NO padding."""
         import torch
         assert return_tensors == "pt" and max_length
+        self.cap.encode_plus_calls.append([text, text_pair, max_length])  # what the reference's EmDataset hands to its tokenizer (encode_datasets.py:95)
         bos, eos = self.tok.bos_token_id, self.tok.eos_token_id
         ia, ib = self._bpe(text), (self._bpe(text_pair) if text_pair is not None else None)
         over = len(ia) + (len(ib) if ib is not None else 0) + (4 if ib is not None else 2) - max_length
@@ -333,9 +361,14 @@ ENCODE_MAX_C_LEN, ENCODE_BATCH = 30, 50
 ENCODE_ROWS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 49, 50, 51, 77, 99, 100, 130, 150, 199, 200, 201, 255, 256)  # embedding rows kept in the fixture (5, 77, 130, 200: empty text)
 
 
-def encode_argv(a, save):
-    return ["--do_predict", "--predict_batch_size", str(ENCODE_BATCH), "--model_name", a["model_dir"], "--predict_file", a["corpus_jsonl"], "--init_checkpoint", a["ckpt"],
-            "--embed_save_path", save, "--fp16", "--max_c_len", str(ENCODE_MAX_C_LEN), "--num_workers", "0"]
+ENCODE_MAX_Q_LEN = 14  # --max_q_len of the --is_query_embed run (what its sequences are cut at)
+# the branches of EmDataset no fixture executed before round 6: (name, asset key of --predict_file, extra flags)
+ENCODE_VARIANTS = [("tsv", "corpus_tsv", []), ("fever", "corpus_fever", []), ("query_embed", "queries_embed", ["--is_query_embed", "--max_q_len", str(ENCODE_MAX_Q_LEN)])]
+
+
+def encode_argv(a, save, predict_file=None, extra=()):
+    return ["--do_predict", "--predict_batch_size", str(ENCODE_BATCH), "--model_name", a["model_dir"], "--predict_file", predict_file or a["corpus_jsonl"],
+            "--init_checkpoint", a["ckpt"], "--embed_save_path", save, "--fp16", "--max_c_len", str(ENCODE_MAX_C_LEN), "--num_workers", "0"] + list(extra)
 
 
 def run_reference_encode_corpus(argv):
@@ -348,7 +381,7 @@ def run_reference_encode_corpus(argv):
         sys.argv = [ENCODE_SCRIPT] + argv
         torch.manual_seed(0)
         runpy.run_path(ENCODE_SCRIPT, run_name="__main__")
-    return out.getvalue()
+    return out.getvalue(), cap
 
 
 def main():
@@ -406,7 +439,7 @@ def main():
         print(f"fever case {fi}: beam {b1} x {b2} topk {topk}: {len(lines)} records, {sum(map(len, lines))} JSONL bytes, {n_inf} empty passages in hop-1 beams")
     # ---- the corpus encoder (scripts/encode_corpus.py: EmDataset -> DataLoader(em_collate) -> RobertaCtxEncoder -> np.save + id2doc.json) ----
     save = os.path.join(tmp, "emb")
-    stdout = run_reference_encode_corpus(encode_argv(a, save))
+    stdout, ecap = run_reference_encode_corpus(encode_argv(a, save))
     emb = np.load(save + ".npy")
     assert emb.shape == (N_DOCS, 768) and emb.dtype == np.float32
     meta["encode_corpus"] = {"max_c_len": ENCODE_MAX_C_LEN, "predict_batch_size": ENCODE_BATCH, "rows": list(ENCODE_ROWS), "shape": list(emb.shape),
@@ -414,7 +447,34 @@ def main():
                              "stdout": [ln.replace(tmp, "<assets>") for ln in stdout.split("\n") if ln and "it/s]" not in ln and not ln.startswith("\r")]}
     arrays["encode.rows"] = emb[list(ENCODE_ROWS)]
     arrays["encode.norms"] = np.linalg.norm(emb, axis=1).astype(np.float32)
+    # what the reference's EmDataset handed to its tokenizer for the passages with special titles / texts: [title argument, text_pair argument, max_length]
+    meta["encode_corpus"]["encode_plus_args"] = {str(i): ecap.encode_plus_calls[i] for i in sorted(set(TITLE_OVERRIDES) | set(TEXT_SUFFIXES) | set(EMPTY_DOCS))}
+    assert len(ecap.encode_plus_calls) == N_DOCS
     print(f"encode_corpus: {emb.shape}, stdout {meta['encode_corpus']['stdout']}")
+    # ---- EmDataset's other branches (encode_datasets.py:52-72): TSV reader, "fever" in the path, --is_query_embed ----
+    meta["encode_variants"] = {}
+    for name, key, extra in ENCODE_VARIANTS:
+        vsave = os.path.join(tmp, "emb_" + name)
+        vout, vcap = run_reference_encode_corpus(encode_argv(a, vsave, a[key], extra))
+        vemb = np.load(vsave + ".npy")
+        idp = os.path.join(vsave, "id2doc.json")
+        meta["encode_variants"][name] = {
+            "predict_file": os.path.basename(a[key]), "extra_flags": extra, "shape": list(vemb.shape),
+            "id2doc_json_sha256": hashlib.sha256(open(idp, "rb").read()).hexdigest() if os.path.exists(idp) else None,
+            "id2doc_written": os.path.exists(idp), "save_dir_created": os.path.isdir(vsave),
+            "embeddings_equal_jsonl_run": bool(vemb.shape == emb.shape and np.array_equal(vemb, emb)),
+            "encode_plus_args_sha256": hashlib.sha256(json.dumps(vcap.encode_plus_calls).encode()).hexdigest(),
+            "encode_plus_args_head": vcap.encode_plus_calls[:3], "n_items": len(vcap.encode_plus_calls),
+            "stdout": [ln.replace(tmp, "<assets>") for ln in vout.split("\n") if ln and "it/s]" not in ln and not ln.startswith("\r")]}
+        arrays[f"encode.{name}.rows"] = vemb[:8]
+        print(f"encode_corpus [{name}]: {vemb.shape}, id2doc written {os.path.exists(idp)}, equal to the JSONL run {meta['encode_variants'][name]['embeddings_equal_jsonl_run']}")
+    # ---- --topk > beam^2 (eval_mhop_retrieval.py:197-198: ranked_pairs has beam^2 rows) ----
+    try:
+        run_reference(cli_argv(a, 2, 5, "list", [], os.path.join(tmp, "paths_topk_too_large.jsonl")))
+        meta["topk_exceeds_beam_squared"] = {"beam": 2, "topk": 5, "raised": None}
+    except Exception as e:  # noqa: BLE001 -- the TYPE is the captured fact
+        meta["topk_exceeds_beam_squared"] = {"beam": 2, "topk": 5, "raised": type(e).__name__, "message": str(e)}
+    print("topk > beam^2:", meta["topk_exceeds_beam_squared"])
     with open(os.path.join(GOLD, "cli_ref.json"), "w") as f:
         json.dump(meta, f, indent=1, ensure_ascii=False)
     np.savez_compressed(os.path.join(GOLD, "cli_ref.npz"), **arrays)

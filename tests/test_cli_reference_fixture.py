@@ -214,3 +214,86 @@ def test_em_dataset_reproduces_the_reference_encode_corpus_scripts_id2doc_and_to
     out = capsys.readouterr().out.split("\n")
     want_lines = [ln.replace("<assets>", os.path.dirname(assets["corpus_jsonl"])) for ln in meta["stdout"][:-1]]  # (the last line is the script's print(embeds.size()))
     assert [ln for ln in out if ln] == want_lines
+
+
+def _em_dataset_calls(monkeypatch, data, ds):
+    """What data.EmDataset hands to the tokenisation for every item: [title argument, text argument, max_length] (the product's counterpart of the reference's
+    `tokenizer.encode_plus(normalize(title.strip()), text_pair=text.strip(), max_length=...)`, encode_datasets.py:95)."""
+    calls = []
+    real = data.encode_pairs_2_11
+
+    def spy(tokenizer, firsts, seconds, max_length, pad):
+        calls.extend([a, b, max_length] for a, b in zip(firsts, seconds))
+        return real(tokenizer, firsts, seconds, max_length, pad)
+
+    monkeypatch.setattr(data, "encode_pairs_2_11", spy)
+    for i in range(len(ds)):
+        ds[i]
+    return calls
+
+
+def test_em_dataset_hands_the_tokenizer_what_the_reference_hands_it_for_special_titles_and_texts(golden, assets, tmp_path, monkeypatch):
+    """Round 6: precomposed / combining / blank-padded titles, texts holding `<s>`, `</s>`, `<mask>`, empty texts. The reference's EmDataset was run
+    by oracle/gen_cli_golden.py and the ARGUMENTS of its tokenizer.encode_plus calls captured: the title NFD-normalised and stripped, the text stripped, an empty text
+    replaced by the title, max_length = --max_c_len. data.EmDataset must hand over the same strings; id2doc.json keeps the RAW titles (same bytes, tested above)."""
+    import unicodedata
+    from multihop_dense_retrieval_amd import data
+    meta = golden("cli_ref.json")["encode_corpus"]
+    ds = data.EmDataset(assets["tok"], assets["corpus_jsonl"], 70, meta["max_c_len"], False, str(tmp_path / "emb"))
+    calls = _em_dataset_calls(monkeypatch, data, ds)
+    assert len(calls) == meta["shape"][0]
+    for i, want in meta["encode_plus_args"].items():
+        assert calls[int(i)] == want, i
+    z = meta["encode_plus_args"]["213"][0]
+    assert z == unicodedata.normalize("NFD", "Zürich") and z != "Zürich" and "̈" in z        # precomposed -> decomposed
+    assert meta["encode_plus_args"]["214"][0] == meta["encode_plus_args"]["215"][0]                # "Kraków" and "  Kraków  " meet after strip + NFD
+    assert json.loads(meta["id2doc_json"])["215"][0] == "  Kraków  "                               # the mapping keeps the raw title
+    assert meta["encode_plus_args"]["58"][1].endswith("<s> inner </s> <mask> tail")
+
+
+@pytest.mark.parametrize("name", ["tsv", "fever", "query_embed"])
+def test_em_dataset_other_branches_reproduce_the_reference_scripts_run(golden, assets, tmp_path, capsys, monkeypatch, name):
+    """EmDataset's TSV reader (`id<TAB>text<TAB>title` header row), its `"fever" in data_path` branch and `--is_query_embed` (encode_datasets.py:52-72,82), each executed
+    by the reference's scripts/encode_corpus.py in oracle/gen_cli_golden.py: the same id2doc.json bytes (or none at all for --is_query_embed, whose sequences are cut at
+    --max_q_len), the same printed lines, the same strings handed to the tokenizer."""
+    from multihop_dense_retrieval_amd import data
+    v = golden("cli_ref.json")["encode_variants"][name]
+    key = {n: k for n, k, _ in gen_cli_golden.ENCODE_VARIANTS}[name]
+    qe = "--is_query_embed" in v["extra_flags"]
+    save = tmp_path / ("emb_" + name)
+    ds = data.EmDataset(assets["tok"], assets[key], gen_cli_golden.ENCODE_MAX_Q_LEN if qe else 70, gen_cli_golden.ENCODE_MAX_C_LEN, qe, str(save))
+    assert os.path.isdir(save) == v["save_dir_created"]
+    assert os.path.exists(save / "id2doc.json") == v["id2doc_written"]
+    if v["id2doc_written"]:
+        assert hashlib.sha256(open(save / "id2doc.json", "rb").read()).hexdigest() == v["id2doc_json_sha256"]
+    calls = _em_dataset_calls(monkeypatch, data, ds)
+    assert len(calls) == v["n_items"] == v["shape"][0]
+    assert calls[:3] == v["encode_plus_args_head"]
+    assert hashlib.sha256(json.dumps(calls).encode()).hexdigest() == v["encode_plus_args_sha256"]
+    out = [ln for ln in capsys.readouterr().out.split("\n") if ln]
+    assert out == [ln.replace("<assets>", os.path.dirname(assets[key])) for ln in v["stdout"][:-1]]  # (the last line is the script's print(embeds.size()))
+    if name != "query_embed":  # same passages as the JSONL corpus: the reference script wrote the very same embeddings
+        assert v["embeddings_equal_jsonl_run"]
+
+
+def test_topk_beyond_beam_squared_raises_what_the_reference_raises(golden):
+    """eval_mhop_retrieval.py:197-198 indexes ranked_pairs[_] for _ < topk: --topk 5 with --beam-size 2 dies with an IndexError in the reference's own run
+    (captured by oracle/gen_cli_golden.py); the drop-in's path ranking raises the same type."""
+    cap = golden("cli_ref.json")["topk_exceeds_beam_squared"]
+    assert cap["raised"] == "IndexError" and cap["beam"] ** 2 < cap["topk"]
+    D, I = np.zeros((1, 2), np.float32), np.zeros((1, 2), np.int64)
+    D2, I2 = np.zeros((2, 2), np.float32), np.zeros((2, 2), np.int64)
+    for rank in (mhop.rank_paths, mhop_oracle.rank_paths):
+        with pytest.raises(IndexError):
+            rank(D, I, D2, I2, cap["beam"], cap["topk"])
+
+
+def test_question_strip_keeps_the_blank_before_a_stripped_question_mark(golden, assets):
+    """`"... born ?"` -> `"... born "` (ONE trailing "?" removed, nothing else: eval_mhop_retrieval.py:139) and leading blanks stay: the reference script's own
+    `questions` list says so; what 2.11's tokenizer then makes of the trailing blank is the open question scripts/parity_with_assets.sh answers."""
+    enc = golden("cli_ref.json")["cases"][0]["questions_encoded"]
+    qs = assets["questions"]
+    i, j = gen_cli_golden.Q_TRAILING_BLANK, gen_cli_golden.Q_LEADING_BLANKS
+    assert qs[i]["question"].endswith(" ?") and enc[i] == qs[i]["question"][:-1] and enc[i].endswith(" ")
+    assert qs[j]["question"].startswith("  ") and enc[j].startswith("  ") and enc[j] == mhop.strip_question(qs[j]["question"])
+    assert [mhop.strip_question(q["question"]) for q in qs] == enc

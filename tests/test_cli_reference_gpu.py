@@ -177,3 +177,39 @@ def test_encode_corpus_cli_against_the_reference_encode_corpus_scripts_run(golde
     assert err.max() <= 1.5e-2 and cos.min() >= 0.99999 and nerr.max() <= 5e-3  # measured: 4.4e-3 / 0.999999 / 5.4e-4 (2-layer toy encoder; the north star allows 1e-2 on inner products of unit-scale vectors)
     for ln in meta["stdout"]:
         assert ln.replace("<assets>", os.path.dirname(assets["corpus_jsonl"])) in out, ln
+
+
+@pytest.mark.parametrize("name", ["tsv", "fever", "query_embed"])
+def test_encode_corpus_cli_other_input_branches_against_the_reference_scripts_run(golden, assets, tmp_path, capsys, name):
+    """Round 6: the corpus-encoder drop-in on a TSV corpus, on a corpus whose path contains "fever" and with --is_query_embed, against what the
+    reference's scripts/encode_corpus.py wrote for the same files (oracle/gen_cli_golden.py ENCODE_VARIANTS): id2doc.json bytes (none for --is_query_embed), shape,
+    printed lines, the first rows of the .npy within the apex-O1-class noise of the HIP encoder."""
+    import hashlib
+    from multihop_dense_retrieval_amd import encode_corpus
+    v, z = golden("cli_ref.json")["encode_variants"][name], golden("cli_ref.npz")
+    key = {n: k for n, k, _ in gen_cli_golden.ENCODE_VARIANTS}[name]
+    save = str(tmp_path / ("emb_" + name))
+    path = encode_corpus.main(gen_cli_golden.encode_argv(assets, save, assets[key], v["extra_flags"]), tokenizer=assets["tok"])
+    out = capsys.readouterr().out
+    emb = np.load(path)
+    assert path == save + ".npy" and list(emb.shape) == v["shape"] and emb.dtype == np.float32
+    idp = os.path.join(save, "id2doc.json")
+    assert os.path.exists(idp) == v["id2doc_written"]
+    if v["id2doc_written"]:
+        assert hashlib.sha256(open(idp, "rb").read()).hexdigest() == v["id2doc_json_sha256"]
+    want = z[f"encode.{name}.rows"]
+    err = np.abs(emb[:len(want)] - want)
+    cos = (emb[:len(want)] * want).sum(1) / (np.linalg.norm(emb[:len(want)], axis=1) * np.linalg.norm(want, axis=1))
+    print(f"encode_corpus [{name}] vs the reference script's fp32 run: max |d| {err.max():.3e}; min cosine {cos.min():.6f}")
+    assert err.max() <= 1.5e-2 and cos.min() >= 0.99999
+    for ln in v["stdout"]:
+        assert ln.replace("<assets>", os.path.dirname(assets[key])) in out, ln
+
+
+def test_cli_topk_beyond_beam_squared_raises_what_the_reference_raises(golden, assets, tmp_path):
+    """--topk 5 with --beam-size 2: the reference's script dies with an IndexError at :197-198 (captured); so does the drop-in CLI."""
+    from multihop_dense_retrieval_amd import eval_mhop_retrieval
+    cap = golden("cli_ref.json")["topk_exceeds_beam_squared"]
+    argv = gen_cli_golden.cli_argv(assets, cap["beam"], cap["topk"], "list", [], str(tmp_path / "p.jsonl")) + ["--num-workers", "0"]
+    with pytest.raises(IndexError):
+        eval_mhop_retrieval.main(argv, tokenizer=assets["tok"])
