@@ -75,10 +75,12 @@ struct mdr_index {
     float* centre = nullptr; // [3 d] c | 1/w | w: centre and per-column scale of the int8 plane (col_sum_kernel), (0, 1, 1) until the first add() sets
                              // them, frozen afterwards; [3 d .. 5 d) scratch for the column sums
     bool centre_set = false;
+    bool cb = false;         // the int8 tier scores the plane against q - lambda c (mdr_mips_screen_i8.inl "Query split"): decided with the centre (flags[11])
     int xexp = 0;            // F32X2H: the planes hold x * 2^-xexp (see convert_to_frag_kernel); fitted to the data by add(), grown by a rescale
     bool xexp_set = false;
     int* flags = nullptr;    // device ints: [0] range error seen by add(), [1] same for queries (ignored), [2] max row |x|^2 (float bits),
-                             // [8], [9] int8 tier: max row scale, max s_r (L1(x8_r)/2 + d/4) (float bits)
+                             // [8], [9], [10] int8 tier: max row scale, max s_r (L1(x8_r)/2 + d/4), max sum|c_i (x_i - c_i)| (float bits);
+                             // [11] the centre is large against the rows' spread around it (centre_finish_kernel) -> cb
     void* stage = nullptr;   // device staging for host-sourced add()
     size_t stage_bytes = 0;
     // pipelined host upload (upload_host_rows): two pinned staging buffers, a copy stream, "chunk copied" / "chunk converted" events per slot
@@ -176,7 +178,7 @@ int launch_add(mdr_index* h, const T* src_dev, long long n, long long row0, hipS
             MDR_HIP_TRY(hipMemsetAsync(sums, 0, (size_t)h->d * 8, st));
             const unsigned gy = (unsigned)((nc + 3) / 4 < 256 ? (nc + 3) / 4 : 256);
             hipLaunchKernelGGL(col_sum_kernel<T>, dim3((unsigned)((h->d + 63) / 64), gy), dim3(256), 0, st, src_dev, nc, h->d, sums);
-            hipLaunchKernelGGL(centre_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)sums, h->d, 1.0f / (float)nc, h->centre);
+            hipLaunchKernelGGL(centre_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)sums, h->d, 1.0f / (float)nc, h->centre, h->flags + 11);
             h->centre_set = true;
         }
         const long long want = (n + 3) / 4, cap = (long long)h->num_cus * 32;  // a wave walks rows r, r + 4 * grid, ...: centre and weights stay in registers
@@ -300,7 +302,7 @@ struct SearchPlan {
     int G8w;  // workgroups of its 32-queries-per-wave kernel
     int G8;   // its workgroups: TWO per CU (24.25 KiB super-blocks: three slots are 73 KiB), one's barrier and epilogue under the other's MFMAs.
               // Measured at 5 M rows, planted queries, whole call: 1 per CU 1.013 ms, 1 per CU with 64-row stages 0.995 ms, 2 per CU 0.907 ms.
-    size_t off_q8, off_qab, off_ctl8, off_gstar;
+    size_t off_q8, off_qab, off_qlam, off_ctl8, off_gstar;
     size_t off_zero, zero_bytes, off_gmax_b;  // the k = 1 screen path's zero block (make_plan)
 };
 
@@ -313,6 +315,11 @@ struct SearchPlan {
 // variant 4 = the screen path WITHOUT the int8 tier (tests and A/B runs)
 // (run_screen8 serves ONE group of at most kStreamQ queries; more than that goes to the 32-queries-per-wave kernel, which loops over
 // groups of 256 -- or, with MDR_MIPS_WIDE=0, stays on the fp16 screen, which loops over groups of 128)
+// MDR_MIPS_I8_CB = 0 / 1 forces the query split of the int8 tier off / on (A/B runs; results are the same either way: any lambda is correct)
+bool use_cb(const mdr_index* h) {
+    static const int force = getenv("MDR_MIPS_I8_CB") ? atoi(getenv("MDR_MIPS_I8_CB")) : -1;
+    return force < 0 ? h->cb : force != 0;
+}
 bool i8_tier(const mdr_index* h, int path, int nq, int k) {
     return h->i8 != nullptr && h->variant != 4 && path == PATH_SCREEN && k == 1 && nq < 65536 && (nq <= kStreamQ || wide_pass(nq));
 }
@@ -378,6 +385,7 @@ SearchPlan make_plan(const mdr_index* h, int nq, int k) {
     p.off_kth = take(slots * 8);
     p.off_q8 = take(p.i8 ? nq_pad * h->d : 0);
     p.off_qab = take(p.i8 ? nq_pad * 16 : 0);
+    p.off_qlam = take(p.i8 ? nq_pad * 4 : 0);  // lambda_q of the query split
     p.total = o + 256;
     return p;
 }
@@ -435,11 +443,13 @@ int run_screen(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, 
 }
 
 // k == 1, at most 128 queries, int8 plane present: the int8 tier (sample pass, main pass, exact re-scoring of its candidates)
+template <bool CB>
 int run_screen8(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, u64* best, hipStream_t st) {
     constexpr int NKB8 = 12, NS = MDR_I8_SLOTS;
     const size_t lds_bytes = NS * (size_t)(2 * NKB8 * kFragBytes + kI8Tail);
-    int rc_ = ensure_dynamic_lds((const void*)mips_screen8_kernel<NKB8, 0, NS>, (int)lds_bytes);
-    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen8_kernel<NKB8, 1, NS>, (int)lds_bytes);
+    int rc_ = ensure_dynamic_lds((const void*)mips_screen8_kernel<NKB8, 0, NS, CB>, (int)lds_bytes);
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen8_kernel<NKB8, 1, NS, CB>, (int)lds_bytes);
+    const float* qlam = (const float*)(ws + p.off_qlam);
     if (rc_) return rc_;
     unsigned* gmax = (unsigned*)(ws + p.off_gmax);
     u64* scand = (u64*)(ws + p.off_scand);
@@ -451,12 +461,12 @@ int run_screen8(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev,
     u64* gstar = (u64*)(ws + p.off_gstar);
     // (gmax, gstar and ctl8 are part of the search call's zero block: cleared once by mdr_index_search)
     // (q8 / qab were written by prep_queries_both_kernel, together with the fp16 fragments: mdr_index_search)
-    hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 0, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
-                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar, (const u64*)best);
+    hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 0, NS, CB>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
+                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar, (const u64*)best, qlam);
     // the sample pass's best-lower-bound rows, re-scored exactly: a first `known` that is up to 2 B tighter than their lower bounds
     hipLaunchKernelGGL(mips_star8_kernel, dim3((nq + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)gstar, nq, best, row_unscale(h));
-    hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 1, NS>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
-                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar, (const u64*)best);
+    hipLaunchKernelGGL((mips_screen8_kernel<NKB8, 1, NS, CB>), dim3(p.G8), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, (const char*)q8,
+                       (const f32x4*)qab, nq, 0, gmax, scand, wave_cnt, ctl8, gstar, (const u64*)best, qlam);
     hipLaunchKernelGGL(mips_star8_kernel, dim3((nq + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)gstar, nq, best, row_unscale(h));
     hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8 * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
                        (const int*)wave_cnt, (const unsigned*)gmax, best, ctl8, kI8RefinePerQuery * nq, (const f32x4*)qab, row_unscale(h));
@@ -497,11 +507,13 @@ int run_screen32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
 }
 
 // k == 1, more than 128 queries, int8 plane present: the int8 tier per group of 256 queries
+template <bool CB>
 int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev, int nq, u64* best, hipStream_t st) {
     constexpr int NKB8 = 12, NS = MDR_I8W_SLOTS;
     const size_t lds_bytes = NS * 2 * (size_t)(2 * NKB8 * kFragBytes + kI8Tail);  // a stage of this kernel = two super-blocks
-    int rc_ = ensure_dynamic_lds((const void*)mips_screen8w_kernel<NKB8, 0, NS>, (int)lds_bytes);
-    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen8w_kernel<NKB8, 1, NS>, (int)lds_bytes);
+    int rc_ = ensure_dynamic_lds((const void*)mips_screen8w_kernel<NKB8, 0, NS, CB>, (int)lds_bytes);
+    if (!rc_) rc_ = ensure_dynamic_lds((const void*)mips_screen8w_kernel<NKB8, 1, NS, CB>, (int)lds_bytes);
+    const float* qlam = (const float*)(ws + p.off_qlam);
     if (rc_) return rc_;
     unsigned* gmax = (unsigned*)(ws + p.off_gmax);
     u64* scand = (u64*)(ws + p.off_scand);
@@ -520,12 +532,12 @@ int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
         const size_t g0 = (size_t)gq.q0;
         const char* qg = q8 + g0 * h->d;
         if (gi) MDR_HIP_TRY(hipMemsetAsync(ctl8 + 3, 0, sizeof(int), st));  // emitted-candidate total of this group's pass
-        hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 0, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
-                           (const f32x4*)(qab + g0), nqg, gq.q0, gmax + g0, scand, wave_cnt, ctl8, gstar + g0, (const u64*)best);
+        hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 0, NS, CB>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
+                           (const f32x4*)(qab + g0), nqg, gq.q0, gmax + g0, scand, wave_cnt, ctl8, gstar + g0, (const u64*)best, qlam + g0);
         hipLaunchKernelGGL(mips_star8_kernel, dim3((nqg + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb,
                            q_dev + g0 * h->d, (const u64*)(gstar + g0), nqg, best + g0, row_unscale(h));
-        hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 1, NS>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
-                           (const f32x4*)(qab + g0), nqg, gq.q0, gmax + g0, scand, wave_cnt, ctl8, gstar + g0, (const u64*)best);
+        hipLaunchKernelGGL((mips_screen8w_kernel<NKB8, 1, NS, CB>), dim3(p.G8w), dim3(512), lds_bytes, st, (const char*)h->i8, (long long)h->ntotal, n_sb, qg,
+                           (const f32x4*)(qab + g0), nqg, gq.q0, gmax + g0, scand, wave_cnt, ctl8, gstar + g0, (const u64*)best, qlam + g0);
         hipLaunchKernelGGL(mips_star8_kernel, dim3((nqg + 15) / 16), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb,
                            q_dev + g0 * h->d, (const u64*)(gstar + g0), nqg, best + g0, row_unscale(h));
         hipLaunchKernelGGL(mips_refine8_kernel, dim3(p.G8w * 8), dim3(256), 0, st, (const char*)h->hi, (const char*)h->lo, h->nkb, q_dev, (const u64*)scand,
@@ -857,7 +869,7 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
     hipStream_t st = (hipStream_t)stream;
     int rc = grow(h, h->ntotal + n, st);
     if (rc) return rc;
-    int before[16] = {0};  // [0..3] range / query / norm flags, [8..9] the int8 tier's row statistics: all restored when the rows are rejected
+    int before[16] = {0};  // [0..3] range / query / norm flags, [8..11] the int8 tier's row statistics and its query-split verdict: all restored when the rows are rejected
     const bool centre_was_set = h->centre_set;
     const int xexp_was = h->xexp;
     const bool xexp_was_set = h->xexp_set;
@@ -871,6 +883,7 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
         (void)hipMemcpyAsync(h->flags, before, sizeof(before), hipMemcpyHostToDevice, st);
         (void)hipStreamSynchronize(st);
         h->centre_set = centre_was_set;
+        h->cb = before[11] != 0;
         if (!xexp_was_set) { h->xexp = xexp_was; h->xexp_set = false; }  // the exponent was fitted to rejected rows: forget it
         return code;
     };
@@ -882,10 +895,11 @@ int mdr_index_add(mdr_index* h, const void* rows, int64_t n, int src_dtype, int 
         rc = upload_host_rows(h, (const char*)rows, n, src_dtype, row_src, st);
         if (rc) return reject(rc);
     }
-    int flag = 0;
-    MDR_HIP_TRY(hipMemcpyAsync(&flag, h->flags, sizeof(int), hipMemcpyDeviceToHost, st));
+    int after[16] = {0};
+    MDR_HIP_TRY(hipMemcpyAsync(after, h->flags, sizeof(after), hipMemcpyDeviceToHost, st));
     MDR_HIP_TRY(hipStreamSynchronize(st));
-    if (flag) return reject(set_error(MDR_E_RANGE, "add(): a value is non-finite; rows were not added"));
+    if (after[0]) return reject(set_error(MDR_E_RANGE, "add(): a value is non-finite; rows were not added"));
+    h->cb = after[11] != 0;  // (written once, with the centre: centre_finish_kernel)
     h->ntotal += n;
     return MDR_OK;
 }
@@ -1013,7 +1027,7 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
             const int nq_pad8 = wide_pass(nq) ? nq_pad : kStreamQ;  // what run_screen8w / run_screen8 read: whole groups of 256 / one group of 128 queries
             const int nb16 = (nq_pad + 3) / 4, nb8 = (nq_pad8 + 3) / 4;
             hipLaunchKernelGGL(prep_queries_both_kernel, dim3(nb16 + nb8), dim3(256), 0, st, nb16, q_dev, nq, nq_pad, nq_pad8, h->d, h->flags, c, qhi, qlo, bound, qscale,
-                               row_unscale(h), ws + p.off_q8, (f32x4*)(ws + p.off_qab), (const float*)h->centre);
+                               row_unscale(h), ws + p.off_q8, (f32x4*)(ws + p.off_qab), (const float*)h->centre, (int)use_cb(h), (float*)(ws + p.off_qlam));
         } else
             hipLaunchKernelGGL((prep_queries_kernel<false>), dim3((nq_pad + 3) / 4), dim3(256), 0, st, q_dev, nq, nq_pad, h->d, h->flags, c, qhi, qlo, bound, qscale,
                                row_unscale(h));
@@ -1026,14 +1040,14 @@ int mdr_index_search(mdr_index* h, const float* q_dev, int nq, int k, float* D_d
         const int* run_if = nullptr;
         if (p.path == PATH_SCREEN) {
             if (wide_pass(nq) && p.i8) {  // int8 tier, 256 queries per pass; the fp16 wide screen only behind an overflow
-                rc = run_screen8w(h, p, ws, q_dev, nq, best, st);
+                rc = use_cb(h) ? run_screen8w<true>(h, p, ws, q_dev, nq, best, st) : run_screen8w<false>(h, p, ws, q_dev, nq, best, st);
                 if (!rc) rc = run_screen32<false>(h, p, ws, q_dev, nq, qhi, best, st, (const int*)(ws + p.off_ctl8));
                 h->last_kernel = "mips_screen8w_kernel<12,1>";
             } else if (wide_pass(nq)) {  // more than 128 queries: 256 per corpus pass on the 32-queries-per-wave kernel
                 rc = bf ? run_screen32<true>(h, p, ws, q_dev, nq, qhi, best, st) : run_screen32<false>(h, p, ws, q_dev, nq, qhi, best, st);
                 h->last_kernel = bf ? "mips_screen32_kernel<24,1,bf16>" : "mips_screen32_kernel<24,1>";
             } else if (p.i8) {  // int8 tier first; the fp16 screen only if one of its lists overflowed, the exact pass only if that one's did
-                rc = run_screen8(h, p, ws, q_dev, nq, best, st);
+                rc = use_cb(h) ? run_screen8<true>(h, p, ws, q_dev, nq, best, st) : run_screen8<false>(h, p, ws, q_dev, nq, best, st);
                 if (!rc) rc = run_screen<false>(h, p, ws, q_dev, nq, qhi, best, st, (const int*)(ws + p.off_ctl8));
                 h->last_kernel = "mips_screen8_kernel<12,1>";
             } else {
@@ -1162,7 +1176,7 @@ int mdr_index_search_telemetry(const mdr_index* h, int nq, int k, const void* wo
         int kept = 0;
         MDR_HIP_TRY(hipMemcpyAsync(&kept, ws + p.off_ctl8 + sizeof(int), sizeof(int), hipMemcpyDeviceToHost, st));
         MDR_HIP_TRY(hipStreamSynchronize(st));
-        out4_host[3] |= 512 | (o8 ? 256 : 0) | ((int64_t)kept << 16);  // bits 16..: candidates of the int8 tier that were really re-scored
+        out4_host[3] |= 512 | (o8 ? 256 : 0) | (use_cb(h) ? 1024 : 0) | ((int64_t)kept << 16);  // bit 10: the query split is on; bits 16..: candidates of the int8 tier that were really re-scored
     }
     return MDR_OK;
 }

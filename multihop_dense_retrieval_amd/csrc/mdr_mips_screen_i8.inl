@@ -14,14 +14,23 @@
 // the fp16 (hi, lo) planes: ids and scores are those of the exact path. If a list overflows (data for which the int8 bound is
 // loose: a large common mean, very heavy tails) the fp16 screen runs behind it, and the exact pass behind that -- each
 // skipped on the device when the tier before it did not overflow.
+// Query split (round 6; `CB` instantiations, chosen per index when its centre is large against the rows' spread around it -- real embedding matrices): a query of
+// the same kind as the rows carries the common component too, q = lambda_q c + dq with lambda_q = (q.c) / (c.c), and quantised whole it spends its 8 bits on
+// lambda_q c (which says nothing about WHICH row wins) instead of on dq. Since
+//     q.(x_r - c) = dq.(x_r - c) + lambda_q b_r,     b_r = c.(x_r - c)  (one fp32 per row, kept beside the row scale in the super-block's tail: no extra bytes),
+// the plane is scored against dq (t, alpha, beta now come from dq: several times smaller) and the per-row term enters the bounds exactly:
+//     U_r = s_r (t A + alpha_q) + beta_q + lambda_q b_r,   L_r = U_r - 2 (alpha_q s_r + beta_q).
+// ANY lambda is correct; fp32 rounding of b_r (768 terms) is covered by |lambda_q| 1e-4 max_r sum_i |c_i (x_ri - c_i)| (i8stats[2]) added to beta_q.
+// Measured at 5 M rows on this repo's encoder outputs (|c| = 26.5, centred rows 9.8): see DESIGN.md section 4.
 // Layout: a super-block (32 rows) = 2 x NKB8 fragment blocks of 1 KiB (16 rows x 64 int8; lane (lr, g) of the MFMA owns the
-// 16 bytes k = 64 kb + 16 g .. of row lr at (16 g + lr) * 16) followed by 256 bytes holding the 32 row scales: 24.25 KiB at
+// 16 bytes k = 64 kb + 16 g .. of row lr at (16 g + lr) * 16) followed by 256 bytes holding the 32 row scales and the 32 row terms b_r: 24.25 KiB at
 // d = 768 against the 48 KiB of the fp16 hi plane.
 #ifndef MDR_I8_ABL
 #define MDR_I8_ABL 0  // measurement builds (wrong results): 1 no scale-tail DMA, 2 no epilogue, 3 no MFMAs, 4 no fragment reads
 #endif
 constexpr int kI8RefinePerQuery = 8192;  // emitted candidates per query of a pass beyond which the int8 tier hands over to the fp16 screen (see mips_refine8_kernel)
-constexpr int kI8Tail = 256;  // bytes behind a super-block's fragments: 32 fp32 row scales (+ padding to one 4-byte-per-lane DMA piece)
+constexpr int kI8Tail = 256;  // bytes behind a super-block's fragments: 32 fp32 row scales, then 32 fp32 row terms b_r = c.(x_r - c): one 4-byte-per-lane DMA piece
+constexpr int kI8TailB = 128;  // offset of the row terms inside the tail
 #ifndef MDR_I8_ALIGN
 #define MDR_I8_ALIGN 256  // variant-build knob: alignment of a super-block's start in the int8 plane
 #endif
@@ -88,7 +97,9 @@ __global__ void __launch_bounds__(256) col_sum_kernel(const T* __restrict__ src,
 // coordinate (A small, B large) is scaled DOWN so that the query's outlier shrinks while the rows' small spread there still resolves; a
 // dense common mean needs nothing on the row side (the centre removes it) and a little on the query side.
 // One block of 1024 threads (d <= 1024).
-__global__ void __launch_bounds__(1024) centre_finish_kernel(const float* __restrict__ sums, int d, float inv_n, float* __restrict__ cw) {
+// *cb_flag = 1 when the centre is large against the spread around it (|c|^2 >= kCbRatio2 x the mean squared distance of a row from c): the query split pays.
+constexpr float kCbRatio2 = 0.02f;
+__global__ void __launch_bounds__(1024) centre_finish_kernel(const float* __restrict__ sums, int d, float inv_n, float* __restrict__ cw, int* __restrict__ cb_flag) {
     __shared__ float red[16];
     __shared__ float bc;
     const int i = threadIdx.x;
@@ -112,7 +123,10 @@ __global__ void __launch_bounds__(1024) centre_finish_kernel(const float* __rest
         var = fmaxf(sums[d + i] * inv_n - mu * mu, 0.f);
         if (!(fabsf(mu) <= 3.0e38f) || !(var <= 3.0e38f)) { mu = 0.f; var = 0.f; }  // (non-finite rows: the add is rejected anyway; keep c and w finite)
     }
-    const float ref = sqrtf(block_reduce(var, false) / (float)d);
+    const float var_sum = block_reduce(var, false);
+    const float mu2_sum = block_reduce(mu * mu, false);
+    if (i == 0) *cb_flag = (mu2_sum >= kCbRatio2 * var_sum && mu2_sum > 0.f) ? 1 : 0;
+    const float ref = sqrtf(var_sum / (float)d);
     float A = 0.f, B = 0.f;
     if (i < d && ref > 0.f) {
         const float sd = sqrtf(var);
@@ -134,7 +148,8 @@ __global__ void __launch_bounds__(1024) centre_finish_kernel(const float* __rest
     cw[2 * d + i] = w;
 }
 
-// one wave per row: lanes 0 .. d/16-1 quantise 16 consecutive columns each of x - centre. stats[0] = max s_r, stats[1] = max s_r (L1(x8_r)/2 + d/4)
+// one wave per row: lanes 0 .. d/16-1 quantise 16 consecutive columns each of x - centre. stats[0] = max s_r, stats[1] = max s_r (L1(x8_r)/2 + d/4),
+// stats[2] = max_r sum_i |c_i (x_ri - c_i)| (what the fp32 rounding of the row term b_r = c.(x_r - c) scales with)
 // (non-negative floats, kept as their bit patterns: they order like ints)
 template <typename T>
 __global__ void __launch_bounds__(256) convert_to_i8_kernel(const T* __restrict__ src, long long n, int d, long long row0, char* __restrict__ dst,
@@ -148,16 +163,21 @@ __global__ void __launch_bounds__(256) convert_to_i8_kernel(const T* __restrict_
         cj[j] = on ? centre[lane * 16 + j] : 0.f;
         iw[j] = on ? centre[d + lane * 16 + j] : 0.f;
     }
-    float smax = 0.f, cmax = 0.f;
+    float smax = 0.f, cmax = 0.f, bamax = 0.f;
     for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (long long)gridDim.x * 4) {
         float x[16];
-        float mx = 0.f;
+        float mx = 0.f, br = 0.f, bra = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            x[j] = on ? (load_as_f32<T>(src + r * (long long)d + lane * 16 + j) - cj[j]) * iw[j] : 0.f;  // (x - c) / w
+            const float xc = on ? load_as_f32<T>(src + r * (long long)d + lane * 16 + j) - cj[j] : 0.f;
+            br = fmaf(cj[j], xc, br);
+            bra = fmaf(fabsf(cj[j]), fabsf(xc), bra);
+            x[j] = xc * iw[j];  // (x - c) / w
             mx = fmaxf(mx, fabsf(x[j]));
         }
         mx = wave_max_f(mx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { br += __shfl_xor(br, o); bra += __shfl_xor(bra, o); }
         const float sc = mx > 0.f ? mx / 127.f : 0.f;
         const float inv = mx > 0.f ? 127.f / mx : 0.f;
         int l1 = 0;
@@ -181,13 +201,18 @@ __global__ void __launch_bounds__(256) convert_to_i8_kernel(const T* __restrict_
             const int kb = lane >> 2, g = lane & 3;
             *(i32x4*)(sb + ((size_t)((row >> 4) & 1) * nkb8 + kb) * kFragBytes + (g * 16 + (int)(row & 15)) * 16) = packed;
         }
-        if (lane == 0) *(float*)(sb + (size_t)2 * nkb8 * kFragBytes + (row & 31) * 4) = sc;
+        if (lane == 0) {
+            *(float*)(sb + (size_t)2 * nkb8 * kFragBytes + (row & 31) * 4) = sc;
+            *(float*)(sb + (size_t)2 * nkb8 * kFragBytes + kI8TailB + (row & 31) * 4) = br;
+        }
+        bamax = fmaxf(bamax, bra);
         smax = fmaxf(smax, sc);
         cmax = fmaxf(cmax, sc * (0.5f * (float)l1 + 0.25f * (float)d));
     }
     if (lane == 0) {  // one pair of atomics per wave instead of per row
         if (__float_as_int(smax) > stats[0]) atomicMax(stats + 0, __float_as_int(smax));
         if (__float_as_int(cmax) > stats[1]) atomicMax(stats + 1, __float_as_int(cmax));
+        if (__float_as_int(bamax) > stats[2]) atomicMax(stats + 2, __float_as_int(bamax));
     }
 }
 
@@ -196,27 +221,35 @@ __global__ void __launch_bounds__(256) convert_to_i8_kernel(const T* __restrict_
 // qab[i][3] = q.c + slack (c = the plane's centre): what is subtracted from an EXACT score of a row to get a valid lower bound of its
 // centred score q.(x - c). slack = 1e-4 sum|q_i c_i| + 2e-6 |q.c| covers the fp32 summation of q.c (768 terms) and the fp32 rounding of
 // x - c in convert_to_i8_kernel; the 1e-3 inflation of alpha / beta covers the rest as before.
+// cb != 0 (the index uses the query split): the plane is scored against dq = q - lambda c, lambda = (q.c) / (c.c) -> qlam[i]; cb == 0: lambda = 0, dq = q.
 __device__ __forceinline__ void prep_queries_i8_body(int bx, const float* __restrict__ q, int nq, int nq_pad, int d, const int* __restrict__ stats,
-                                                     char* __restrict__ q8, f32x4* __restrict__ qab, const float* __restrict__ centre) {
+                                                     char* __restrict__ q8, f32x4* __restrict__ qab, const float* __restrict__ centre, int cb,
+                                                     float* __restrict__ qlam) {
     const int lane = threadIdx.x & 63;
     const int i = bx * 4 + (threadIdx.x >> 6);
     if (i >= nq_pad) return;
     const int nkb8 = d >> 6;
     const bool on = lane < (d >> 4) && i < nq;
-    float x[16];
-    float mx = 0.f, qc = 0.f, qca = 0.f;
+    float x[16], cv[16];
+    float mx = 0.f, qc = 0.f, qca = 0.f, cc = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         x[j] = on ? q[(size_t)i * d + lane * 16 + j] : 0.f;
-        const float cj = on ? centre[lane * 16 + j] : 0.f;
-        qc = fmaf(x[j], cj, qc);
-        qca = fmaf(fabsf(x[j]), fabsf(cj), qca);
-        x[j] *= on ? centre[2 * d + lane * 16 + j] : 0.f;  // q_i w_i (w a power of two: exact)
+        cv[j] = on ? centre[lane * 16 + j] : 0.f;
+        qc = fmaf(x[j], cv[j], qc);
+        qca = fmaf(fabsf(x[j]), fabsf(cv[j]), qca);
+        cc = fmaf(cv[j], cv[j], cc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { qc += __shfl_xor(qc, o); qca += __shfl_xor(qca, o); cc += __shfl_xor(cc, o); }
+    float lam = cb && cc > 0.f ? qc / cc : 0.f;
+    if (!(fabsf(lam) <= 3.0e38f)) lam = 0.f;  // (a non-finite query: the bounds below become infinite anyway)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        x[j] = fmaf(-lam, cv[j], x[j]) * (on ? centre[2 * d + lane * 16 + j] : 0.f);  // (q_i - lambda c_i) w_i (w a power of two: exact)
         mx = fmaxf(mx, fabsf(x[j]));
     }
     mx = wave_max_f(mx);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { qc += __shfl_xor(qc, o); qca += __shfl_xor(qca, o); }
     const bool fin = mx <= 3.0e38f;  // a non-finite query gets an infinite bound below: every row becomes a candidate, the lists overflow, the tiers behind decide
     const float t = mx > 0.f && fin ? mx / 127.f : 0.f;
     const float inv = mx > 0.f && fin ? 127.f / mx : 0.f;
@@ -240,10 +273,11 @@ __device__ __forceinline__ void prep_queries_i8_body(int bx, const float* __rest
         *(i32x4*)(q8 + ((size_t)(i >> 4) * nkb8 + kb) * kFragBytes + (g * 16 + (i & 15)) * 16) = packed;
     }
     if (lane == 0) {
-        const float s2 = __int_as_float(stats[1]);
-        f32x4 o = {t, 0.5f * t * (float)l1 * 1.001f, t * s2 * 1.001f, qc + (1e-4f * qca + 2e-6f * fabsf(qc))};
+        const float s2 = __int_as_float(stats[1]), s3 = __int_as_float(stats[2]);
+        f32x4 o = {t, 0.5f * t * (float)l1 * 1.001f, t * s2 * 1.001f + fabsf(lam) * 1e-4f * s3, qc + (1e-4f * qca + 2e-6f * fabsf(qc))};
         if (!fin) o = (f32x4){0.f, INFINITY, INFINITY, 0.f};
         qab[i] = o;
+        qlam[i] = fin ? lam : 0.f;
     }
 }
 
@@ -252,9 +286,9 @@ __device__ __forceinline__ void prep_queries_i8_body(int bx, const float* __rest
 __global__ void __launch_bounds__(256) prep_queries_both_kernel(int nb16, const float* __restrict__ q, int nq, int nq_pad16, int nq_pad8, int d, int* __restrict__ flags,
                                                                 float c, char* __restrict__ qhi, char* __restrict__ qlo, float* __restrict__ bound,
                                                                 float* __restrict__ qscale, float xs, char* __restrict__ q8, f32x4* __restrict__ qab,
-                                                                const float* __restrict__ centre) {
+                                                                const float* __restrict__ centre, int cb, float* __restrict__ qlam) {
     if ((int)blockIdx.x < nb16) prep_queries_body<false>((int)blockIdx.x, q, nq, nq_pad16, d, flags, c, qhi, qlo, bound, qscale, xs);
-    else prep_queries_i8_body((int)blockIdx.x - nb16, q, nq, nq_pad8, d, (const int*)(flags + 8), q8, qab, centre);
+    else prep_queries_i8_body((int)blockIdx.x - nb16, q, nq, nq_pad8, d, (const int*)(flags + 8), q8, qab, centre, cb, qlam);
 }
 
 template <int NKB8>
@@ -270,12 +304,13 @@ __device__ __forceinline__ void issue_super_block8(const char* __restrict__ X8, 
 }
 
 // MODE 0: sample pass (publish the largest lower bound per query to gmax); MODE 1: main pass (candidates). See mips_screen_kernel.
-template <int NKB8, int MODE, int NS>  // NS: LDS slots of one super-block (NS - 1 stages in flight)
+template <int NKB8, int MODE, int NS, bool CB = false>  // NS: LDS slots of one super-block (NS - 1 stages in flight); CB: the query split (header of this file)
 __global__ void __launch_bounds__(512, 2)
 mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, const char* __restrict__ Q8, const f32x4* __restrict__ qab, int nq, int q_base,
                     unsigned* __restrict__ gmax /* [nq] ordered(max L) */, u64* __restrict__ cand /* [waves][kWaveCandCap] */,
                     int* __restrict__ cand_cnt /* [waves] */, int* __restrict__ overflow, u64* __restrict__ gstar /* [nq] (ordered max L, its row) */,
-                    const u64* __restrict__ best /* MODE 1: exact keys of the sample pass's star rows (a tighter first `known`) */) {
+                    const u64* __restrict__ best /* MODE 1: exact keys of the sample pass's star rows (a tighter first `known`) */,
+                    const float* __restrict__ qlam /* CB: lambda_q */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SB_BYTES = 2 * NKB8 * kFragBytes + kI8Tail;
     constexpr int CPW = NKB8 / 4;  // DMA pieces per wave and stage (wave 0: + 1, the scale tail)
@@ -305,6 +340,7 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
     f32x4 ab = {0.f, 0.f, 0.f, 0.f};
     if (q_valid) ab = qab[qlocal];
     float qt = ab[0], qa = ab[1], qb = ab[2];
+    float ql = CB && q_valid ? qlam[qlocal] : 0.f;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     float known = -FLT_MAX;  // largest lower bound (of the CENTRED score q.(x - c)) known for this lane's query
     if (MODE == 1 && q_valid) {
@@ -316,8 +352,8 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
     // retire every register load before the loop (see mips_screen_kernel)
 #pragma unroll
     for (int kb = 0; kb < NKB8; ++kb) asm volatile("" : "+v"(qh[kb]));
-    asm volatile("" : "+v"(qt), "+v"(qa), "+v"(qb), "+v"(known));
-    const f32x2 qt2 = {qt, qt}, qa2 = {qa, qa}, qb2 = {qb, qb};
+    asm volatile("" : "+v"(qt), "+v"(qa), "+v"(qb), "+v"(known), "+v"(ql));
+    const f32x2 qt2 = {qt, qt}, qa2 = {qa, qa}, qb2 = {qb, qb}, ql2 = {ql, ql};
     const unsigned sub_row = 4u * (unsigned)(lane >> 4);
     float lmax = -FLT_MAX;  // largest lower bound this lane has seen
     unsigned lrow = 0;      // ... and the row it belongs to: the refinement re-scores that row first (see mips_star8_kernel)
@@ -366,6 +402,11 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
         // this lane's 8 row scales: rows 4 g .. 4 g + 3 of both 16-row blocks
         const f32x4 sr0 = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + sub_row * 4);
         const f32x4 sr1 = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + (16 + sub_row) * 4);
+        f32x4 br0 = {0.f, 0.f, 0.f, 0.f}, br1 = br0;  // CB: this lane's 8 row terms b_r
+        if (CB) {
+            br0 = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + kI8TailB + sub_row * 4);
+            br1 = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + kI8TailB + (16 + sub_row) * 4);
+        }
 #pragma unroll
         for (int kb = 0; kb < HK; ++kb) {
             const i32x4 c00 = x00[kb % PF], c01 = x01[kb % PF], c10 = x10[kb % PF], c11 = x11[kb % PF];
@@ -390,8 +431,13 @@ mips_screen8_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, con
         for (int pr = 0; pr < 2; ++pr) {
             const f32x2 f0 = {(float)i0[2 * pr], (float)i0[2 * pr + 1]}, f1 = {(float)i1[2 * pr], (float)i1[2 * pr + 1]};
             const f32x2 s0 = {sr0[2 * pr], sr0[2 * pr + 1]}, s1 = {sr1[2 * pr], sr1[2 * pr + 1]};
-            u2[pr] = __builtin_elementwise_fma(__builtin_elementwise_fma(f0, qt2, qa2), s0, qb2);
-            u2[2 + pr] = __builtin_elementwise_fma(__builtin_elementwise_fma(f1, qt2, qa2), s1, qb2);
+            f32x2 ad0 = qb2, ad1 = qb2;  // beta_q (+ lambda_q b_r)
+            if (CB) {
+                ad0 = __builtin_elementwise_fma((f32x2){br0[2 * pr], br0[2 * pr + 1]}, ql2, qb2);
+                ad1 = __builtin_elementwise_fma((f32x2){br1[2 * pr], br1[2 * pr + 1]}, ql2, qb2);
+            }
+            u2[pr] = __builtin_elementwise_fma(__builtin_elementwise_fma(f0, qt2, qa2), s0, ad0);
+            u2[2 + pr] = __builtin_elementwise_fma(__builtin_elementwise_fma(f1, qt2, qa2), s1, ad1);
         }
         const float up[8] = {u2[0][0], u2[0][1], u2[1][0], u2[1][1], u2[2][0], u2[2][1], u2[3][0], u2[3][1]};
         const unsigned row0 = (unsigned)sb_idx * 32u + sub_row;
@@ -503,11 +549,11 @@ __device__ __forceinline__ i32x16 mfma_chain8x32(const char* p, const i32x4 (&qf
 __device__ unsigned long long g_i8_stamp[8];
 #endif
 
-template <int NKB8, int MODE, int NS>
+template <int NKB8, int MODE, int NS, bool CB = false>
 __global__ void __launch_bounds__(512, 2)
 mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, const char* __restrict__ Q8, const f32x4* __restrict__ qab, int nq, int q_base,
                      unsigned* __restrict__ gmax, u64* __restrict__ cand, int* __restrict__ cand_cnt, int* __restrict__ overflow, u64* __restrict__ gstar,
-                     const u64* __restrict__ best) {
+                     const u64* __restrict__ best, const float* __restrict__ qlam /* CB: lambda_q */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SB_BYTES = 2 * NKB8 * kFragBytes + kI8Tail;
     constexpr int SPS = 2;                   // super-blocks per stage: ONE barrier and one burst of DMA issue per 64 rows
@@ -546,6 +592,7 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
     f32x4 ab = {0.f, 0.f, 0.f, 0.f};
     if (q_valid) ab = qab[qlocal];
     float qt = ab[0], qa = ab[1], qb = ab[2];
+    float ql = CB && q_valid ? qlam[qlocal] : 0.f;
     float known = -FLT_MAX;
     if (MODE == 1 && q_valid) {
         unsigned g = gmax[qlocal];
@@ -555,8 +602,8 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
     }
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) asm volatile("" : "+v"(qf[sl]));
-    asm volatile("" : "+v"(qt), "+v"(qa), "+v"(qb), "+v"(known));
-    const f32x2 qt2 = {qt, qt}, qa2 = {qa, qa}, qb2 = {qb, qb};
+    asm volatile("" : "+v"(qt), "+v"(qa), "+v"(qb), "+v"(known), "+v"(ql));
+    const f32x2 qt2 = {qt, qt}, qa2 = {qa, qa}, qb2 = {qb, qb}, ql2 = {ql, ql};
     float lmax = -FLT_MAX;
     unsigned lrow = 0;  // the row lmax belongs to (see mips_screen8_kernel)
     int my_cnt = 0;
@@ -584,6 +631,12 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
 #pragma unroll
         for (int j = 0; j < 4; ++j) P[h].sr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    // CB: the 16 row terms b_r of the super-block whose epilogue is PENDING. One set serves both accumulator sets (a second one spilled: 266 VGPRs): it is read
+    // from the super-block's own LDS slot behind MFMA 9 of that super-block's chain -- after the previous super-block's epilogue (MFMAs 0-8) has used the old
+    // values, while the slot is still this stage's -- and consumed in the first MFMAs of the next chain.
+    f32x4 brs[CB ? 4 : 1];
+#pragma unroll
+    for (int j = 0; j < (CB ? 4 : 1); ++j) brs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x2 u2[8];
     float mu = -FLT_MAX;
 #pragma unroll
@@ -592,7 +645,9 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
         constexpr int j = decltype(jc)::value;
         const f32x2 f = {(float)R.acc[2 * j], (float)R.acc[2 * j + 1]};
         const f32x2 sc = {R.sr[j >> 1][2 * (j & 1)], R.sr[j >> 1][2 * (j & 1) + 1]};
-        u2[j] = __builtin_elementwise_fma(__builtin_elementwise_fma(f, qt2, qa2), sc, qb2);
+        f32x2 ad = qb2;  // beta_q (+ lambda_q b_r)
+        if constexpr (CB) ad = __builtin_elementwise_fma((f32x2){brs[j >> 1][2 * (j & 1)], brs[j >> 1][2 * (j & 1) + 1]}, ql2, qb2);
+        u2[j] = __builtin_elementwise_fma(__builtin_elementwise_fma(f, qt2, qa2), sc, ad);
         mu = j == 0 ? fmaxf(u2[0][0], u2[0][1]) : fmaxf(mu, fmaxf(u2[j][0], u2[j][1]));
     };
     auto decide = [&](Pending& R) __attribute__((always_inline)) {
@@ -686,6 +741,10 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
                     if constexpr (MDR_I8_ABL != 2) {
                         if constexpr (sl < 8) bounds(Rp, slc);
                         else if constexpr (sl == 8) decide(Rp);
+                        else if constexpr (CB && sl == 9) {  // (in-order LDS returns: the chain's counted waits stay sufficient with these four reads in flight)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) brs[j] = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + kI8TailB + (8 * j + 4 * lh) * 4);
+                        }
                     }
                 });
             }

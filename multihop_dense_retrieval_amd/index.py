@@ -130,12 +130,13 @@ class IndexFlatIP:
         return int(_lib.lib().mdr_index_queries_per_pass(self._h, int(nq), int(k)))
 
     def telemetry(self, nq, k):
-        """Test hook (synchronises): {"fallback", "candidates", "bad_query", "path", "i8_tier", "i8_overflow"} of the last search of this shape."""
+        """Test hook (synchronises): {"fallback", "candidates", "bad_query", "path", "i8_tier", "i8_overflow", "i8_query_split", "i8_refined"} of the last search of this shape."""
         out = (ctypes.c_int64 * 4)()
         _lib.check(_lib.lib().mdr_index_search_telemetry(self._h, int(nq), int(k), ctypes.c_void_p(self._ws.data_ptr()), out,
                                                          _lib.current_stream_ptr(self.device)))
         return {"fallback": int(out[0]), "candidates": int(out[1]), "bad_query": int(out[2]), "path": int(out[3]) & 0xFF,
-                "i8_tier": bool(int(out[3]) & 512), "i8_overflow": bool(int(out[3]) & 256), "i8_refined": int(out[3]) >> 16}
+                "i8_tier": bool(int(out[3]) & 512), "i8_overflow": bool(int(out[3]) & 256), "i8_query_split": bool(int(out[3]) & 1024),
+                "i8_refined": int(out[3]) >> 16}
 
     def set_variant(self, v):
         """Test hook: 0 auto, 1 generic fp32 kernel, 2 exact 3-MFMA stream kernel, 3 screen + refine, 4 screen + refine without the int8 tier."""

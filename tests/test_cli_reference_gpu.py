@@ -79,21 +79,25 @@ def test_cli_chains_against_the_reference_scripts_run(golden, assets, tmp_path, 
         n_equal = sum(a == b for a, b in zip(lines, ref_lines))
     else:
         n_equal = None
-    worst, top_equal, all_equal, pos_equal, overlap = 0.0, 0, 0, 0.0, 0.0
+    worst, top_equal, all_equal, pos_equal, overlap, strict_equal = 0.0, 0, 0, 0.0, 0.0, 0
     for n, ln in enumerate(lines):
         rec = json.loads(ln)
         assert list(rec.keys()) == ["_id", "question", "candidate_chains"] and rec["_id"] == f"q{n}" and len(rec["candidate_chains"]) == topk
         got = [[c[0]["title"], c[1]["title"]] for c in rec["candidate_chains"]]
         want = case["chain_titles"][n]
-        top_equal += got[0] == want[0]
-        all_equal += got == want
-        pos_equal += sum(g == w for g, w in zip(got, want)) / topk
-        overlap += len(set(map(tuple, got)) & set(map(tuple, want))) / len(set(map(tuple, want)))
         # every chain the CLI returned must be one of the script's beam x beam paths or lose to the script's k-th best by less than the noise
         by_title = {}
         for (a, c), s in truth[n].items():
             key = (title_of[a], title_of[c])
             by_title[key] = max(by_title.get(key, -np.inf), s)
+        # "equal" up to EXACT ties of the captured path scores: duplicate corpus rows (gen_cli_golden.DUPLICATE_ROWS) give two chains the same score to the bit, and
+        # the order among equal scores is whatever argsort does (unspecified in the reference, eval_mhop_retrieval.py:190-192)
+        same = [g == w or (by_title.get(tuple(g)) is not None and by_title.get(tuple(g)) == by_title.get(tuple(w))) for g, w in zip(got, want)]
+        top_equal += same[0]
+        all_equal += all(same)
+        strict_equal += got == want
+        pos_equal += sum(same) / topk
+        overlap += len(set(map(tuple, got)) & set(map(tuple, want))) / len(set(map(tuple, want)))
         kth = sorted(truth[n].values(), reverse=True)[topk - 1]
         for g in got:
             s = by_title.get(tuple(g))
@@ -112,7 +116,7 @@ def test_cli_chains_against_the_reference_scripts_run(golden, assets, tmp_path, 
     # the log lines are the reference's, value for value when every chain agrees
     for needle in case["log"][:6]:
         assert needle in err, needle
-    if all_equal == NQ:
+    if strict_equal == NQ:
         tail = case["log"][case["log"].index(f"Evaluating {NQ} samples..."):]
         assert [ln for ln in err.split("\n") if ln][-len(tail):] == tail
         assert metrics == case["metrics"]
