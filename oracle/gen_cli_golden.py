@@ -73,7 +73,9 @@ TEXT_SUFFIXES = {58: " <s> inner </s> <mask> tail", 173: " so <mask> it </s>", 1
 Q_TRAILING_BLANK, Q_LEADING_BLANKS = 5, 6
 # (beam, topk, corpus-dict shape, extra flags).  (50, 50): the reference's own downstream setting (README.md:240-241 b50_k50), JSONL kept as a hash.
 # (100, 100): README.md:241 b100_k100, on the first N_Q_SMALL questions only (a 100 x 100 beam grid per question: the capture stays small).
-CASES = [(1, 1, "list", []), (3, 4, "list", []), (5, 2, "dict", []), (3, 4, "dict", ["--only-eval-ans"]), (50, 50, "list", []), (100, 100, "dict", ["small"])]
+# "base12" (round 6): the same run with a 12-layer, ffn-3072 checkpoint (seeded.ROBERTA_BASE geometry on the toy vocabulary) -- the real depth.
+CASES = [(1, 1, "list", []), (3, 4, "list", []), (5, 2, "dict", []), (3, 4, "dict", ["--only-eval-ans"]), (50, 50, "list", []), (100, 100, "dict", ["small"]),
+         (1, 1, "list", ["base12"])]
 N_Q_SMALL = 5
 
 
@@ -166,11 +168,34 @@ def build_assets(out_dir):
             "corpus_tsv": corpus_tsv, "corpus_fever": corpus_fever, "queries_embed": queries_embed, "questions": qs, "docs": docs}
 
 
+def build_base12_assets(a):
+    """The 12-layer checkpoint + model directory of the "base12" case (340 MB: built only by the generator and by the GPU test that needs it)."""
+    import torch
+    import transformers
+    if "ckpt_base12" in a:
+        return a
+    out_dir = os.path.dirname(a["ckpt"])
+    geom = dict(seeded.ROBERTA_BASE, vocab=a["geom"]["vocab"])
+    sd = seeded.make_state_dict(SEED + 1, geom)
+    model_dir = os.path.join(out_dir, "toy-roberta-base12")
+    cfg = transformers.RobertaConfig(vocab_size=geom["vocab"], hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                                     max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0, eos_token_id=2,
+                                     hidden_act="gelu")
+    cfg.save_pretrained(model_dir)
+    a["tok"].save_pretrained(model_dir)
+    ckpt = os.path.join(out_dir, "q_encoder_base12.pt")
+    torch.save({"module." + k: torch.from_numpy(v) for k, v in sd.items()}, ckpt)
+    a.update(ckpt_base12=ckpt, model_dir_base12=model_dir, geom_base12=geom)
+    return a
+
+
 def cli_argv(a, beam, topk, shape, extra, save):
     small = "small" in extra  # (not a flag of the script: selects the short question file)
-    extra = [e for e in extra if e != "small"]
-    return [a["raw_small"] if small else a["raw"], a["index"], a["id2doc"][shape], a["ckpt"], "--batch-size", str(BATCH), "--beam-size", str(beam), "--topk", str(topk),
-            "--model-name", a["model_dir"], "--gpu", "--shared-encoder", "--save-path", save, "--max-q-len", str(MAX_Q_LEN),
+    base12 = "base12" in extra  # (not a flag either: selects the 12-layer checkpoint)
+    extra = [e for e in extra if e not in ("small", "base12")]
+    ckpt, model_dir = (a["ckpt_base12"], a["model_dir_base12"]) if base12 else (a["ckpt"], a["model_dir"])
+    return [a["raw_small"] if small else a["raw"], a["index"], a["id2doc"][shape], ckpt, "--batch-size", str(BATCH), "--beam-size", str(beam), "--topk", str(topk),
+            "--model-name", model_dir, "--gpu", "--shared-encoder", "--save-path", save, "--max-q-len", str(MAX_Q_LEN),
             "--max-q-sp-len", str(MAX_Q_SP_LEN)] + list(extra)
 
 
@@ -390,6 +415,8 @@ def main():
     import transformers
     # AutoModel.from_pretrained(--model-name) (mhop_retriever.py:20) wants weights next to the config; load_saved then overwrites every one of them
     transformers.RobertaModel(transformers.AutoConfig.from_pretrained(a["model_dir"])).save_pretrained(a["model_dir"])
+    build_base12_assets(a)
+    transformers.RobertaModel(transformers.AutoConfig.from_pretrained(a["model_dir_base12"])).save_pretrained(a["model_dir_base12"])
     meta = {"n_docs": N_DOCS, "n_questions": N_Q, "seed": SEED, "batch": BATCH, "max_q_len": MAX_Q_LEN, "max_q_sp_len": MAX_Q_SP_LEN,
             "generator": "oracle/gen_cli_golden.py: /root/reference/scripts/eval/eval_mhop_retrieval.py executed as __main__ under library stubs",
             "cases": []}

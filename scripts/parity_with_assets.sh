@@ -48,6 +48,20 @@ out["hop2"] = {"input_ids": e["input_ids"].tolist(), "attention_mask": e["attent
 e = tok.batch_encode_plus(pairs, max_length=351, pad_to_max_length=True, return_tensors="pt")                          # odd budget: the slow truncation rule
 out["hop2_odd"] = {"input_ids": e["input_ids"].tolist()}
 out["ctx"] = [tok.encode_plus(d["title"].strip(), text_pair=(d["text"].strip() or d["title"]), max_length=300)["input_ids"] for d in docs]  # encode_datasets.py:95
+# round 6 (VERDICT r5 What's weak 1): the strings whose 2.11 treatment the build could not confirm from memory -- a trailing blank left by the "?" strip (does
+# tokenize()'s split_on_tokens strip it?), leading blanks, the tokenizer's own special-token strings inside a text, precomposed / decomposed titles
+import unicodedata
+probe_q = ["When was the stadium born ", "  where is the river bank", "what is <mask> in <s> text </s> here", "plain question", "tab\tinside and trailing tab\t",
+           "Who founded Zu\u0308rich", "Who founded Z\u00fcrich"]
+probe_p = [("Z\u00fcrich", "Z\u00fcrich is a city <s> inner </s> <mask> tail"), (unicodedata.normalize("NFD", "Krak\u00f3w"), "so <mask> it </s>"),
+           ("  Krak\u00f3w  ", " leading blank and trailing blank "), ("\u00c5ngstr\u00f6m (unit)", "<s>"), ("T", "")]
+out["probe_questions"], out["probe_passages"] = probe_q, [list(x) for x in probe_p]
+e = tok.batch_encode_plus(probe_q, max_length=70, pad_to_max_length=True, return_tensors="pt")
+out["probe_hop1"] = e["input_ids"].tolist()
+pp = [(probe_q[i % len(probe_q)], t if t.strip() else ti) for i, (ti, t) in enumerate(probe_p)]
+e = tok.batch_encode_plus(pp, max_length=40, pad_to_max_length=True, return_tensors="pt")
+out["probe_hop2"] = e["input_ids"].tolist()
+out["probe_ctx"] = [tok.encode_plus(unicodedata.normalize("NFD", ti.strip()), text_pair=(t.strip() or ti), max_length=30)["input_ids"] for ti, t in probe_p]  # encode_datasets.py:95
 json.dump(out, open(gold, "w"))
 print("wrote", gold)
 PY
@@ -72,6 +86,25 @@ ids, _ = encode_pairs_2_11(tok, [d["title"].strip() for d in g["docs"]], [(d["te
 n = sum(a != b for a, b in zip(ids, g["ctx"]))
 print(f"ctx: {n} of {len(ids)} passages differ")
 bad += n
+if "probe_questions" in g:  # the strings of round 6 (trailing / leading blanks, special-token strings, NFD titles): reported one by one
+    import unicodedata
+    pq, pp_ = g["probe_questions"], g["probe_passages"]
+    e = tokenize_2_11(tok, pq, None, 70)
+    for i, (a, b) in enumerate(zip(np.asarray(e["input_ids"]).tolist(), g["probe_hop1"])):
+        if a != b:
+            bad += 1
+            print(f"probe question {pq[i]!r}: ours {[t for t in a if t != 1]} vs 2.11 {[t for t in b if t != 1]}")
+    pairs = [(pq[i % len(pq)], t if t.strip() else ti) for i, (ti, t) in enumerate(pp_)]
+    e = tokenize_2_11(tok, None, pairs, 40)
+    for i, (a, b) in enumerate(zip(np.asarray(e["input_ids"]).tolist(), g["probe_hop2"])):
+        if a != b:
+            bad += 1
+            print(f"probe pair {pairs[i]!r}: ours {[t for t in a if t != 1]} vs 2.11 {[t for t in b if t != 1]}")
+    ids, _ = encode_pairs_2_11(tok, [unicodedata.normalize("NFD", ti.strip()) for ti, t in pp_], [(t.strip() or ti) for ti, t in pp_], 30, False)
+    for i, (a, b) in enumerate(zip(ids, g["probe_ctx"])):
+        if list(a) != list(b):
+            bad += 1
+            print(f"probe passage {pp_[i]!r}: ours {list(a)} vs 2.11 {list(b)}")
 print("tokenisation parity with transformers", g["version"], "OK" if bad == 0 else f"FAILED ({bad} rows)")
 sys.exit(0 if bad == 0 else 1)
 PY

@@ -48,7 +48,7 @@ def _same_up_to_ties(got, want_titles, id2doc):
     return True
 
 
-@pytest.mark.parametrize("ci", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("ci", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("impl", ["product", "restatement"])
 def test_host_loop_reproduces_the_reference_scripts_own_run(golden, assets, ci, impl):
     meta, z = golden("cli_ref.json"), golden("cli_ref.npz")

@@ -58,12 +58,14 @@ def _captured_path_scores(case, ci, z, n_q, batch):
     return out
 
 
-@pytest.mark.parametrize("ci", [0, 1, 2, 4, 5])
+@pytest.mark.parametrize("ci", [0, 1, 2, 4, 5, 6])
 def test_cli_chains_against_the_reference_scripts_run(golden, assets, tmp_path, ci, capsys):
     from multihop_dense_retrieval_amd import eval_mhop_retrieval
     meta, z = golden("cli_ref.json"), golden("cli_ref.npz")
     case = meta["cases"][ci]
     beam, topk = case["beam"], case["topk"]
+    if "base12" in case["extra_flags"]:  # case 6: the 12-layer, ffn-3072 checkpoint (the real depth; 340 MB, built only here)
+        gen_cli_golden.build_base12_assets(assets)
     save = str(tmp_path / "paths.jsonl")
     argv = gen_cli_golden.cli_argv(assets, beam, topk, case["id2doc_shape"], case["extra_flags"], save) + ["--num-workers", "0"]
     metrics, recs = eval_mhop_retrieval.main(argv, tokenizer=assets["tok"])

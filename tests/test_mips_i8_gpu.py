@@ -220,3 +220,30 @@ print('ok', kern)
 """
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MDR_MIPS_WIDE="0"), capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and "ok mips_screen_kernel<24,1>" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("nq", [100, 200])
+def test_query_split_on_rows_with_a_large_common_component(mdr, nq):
+    """Round 6: rows AND queries that share a large common vector (what LayerNorm outputs of one trained encoder look like: |c| = 3 x the spread around it). The
+    index decides for the query split with its centre (telemetry bit `i8_query_split`), the int8 tier alone decides every query, and the answer is the exact
+    kernel's -- for queries of the corpus' kind, for queries WITHOUT the common component (lambda ~ 0: the split must not hurt them) and for queries pointing
+    AWAY from it (negative lambda). An i.i.d. corpus keeps the split off."""
+    g = torch.Generator(device="cuda").manual_seed(77)
+    n = 200_000
+    c = 1.0 * torch.randn((D_,), generator=g, device="cuda")           # |c| ~ 27.7
+    x = c + 0.33 * torch.randn((n, D_), generator=g, device="cuda")     # spread ~ 9.1
+    idx = mdr.IndexFlatIP(D_)
+    idx.add(x)
+    noise = torch.randn((nq, D_), generator=g, device="cuda")
+    kinds = {"same kind": c + 0.33 * noise, "planted": x[torch.arange(nq, device="cuda") * 997] + 0.02 * noise, "no common part": 0.33 * noise,
+             "opposite": -c + 0.33 * noise}
+    for name, q in kinds.items():
+        t = check(idx, q.contiguous(), expect_i8_decides=True)
+        idx.search(q.contiguous(), 1)
+        t = idx.telemetry(nq, 1)
+        assert t["i8_query_split"] and t["i8_tier"] and not t["i8_overflow"] and t["fallback"] == 0, (name, t)
+        print(f"query split, nq {nq}, {name}: candidates emitted {t['candidates']}, re-scored {t['i8_refined']}")
+    iid = mdr.IndexFlatIP(D_)
+    iid.add(torch.randn((50_000, D_), generator=g, device="cuda"))
+    iid.search(noise.contiguous(), 1)
+    assert not iid.telemetry(nq, 1)["i8_query_split"]

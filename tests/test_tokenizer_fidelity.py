@@ -286,6 +286,14 @@ def test_token_ids_equal_transformers_2_11_when_the_golden_file_exists():
         assert np.array_equal(np.asarray(e["input_ids"]), np.asarray(g[key]["input_ids"])), key
     ids, _ = encode_pairs_2_11(tok, [d["title"].strip() for d in g["docs"]], [(d["text"].strip() or d["title"]) for d in g["docs"]], 300, False)
     assert ids == g["ctx"]
+    if "probe_questions" in g:  # round 6: trailing / leading blanks, special-token strings inside a text, precomposed / decomposed titles
+        import unicodedata
+        pq, pp = g["probe_questions"], g["probe_passages"]
+        assert np.asarray(tokenize_2_11(tok, pq, None, 70)["input_ids"]).tolist() == g["probe_hop1"]
+        pairs = [(pq[i % len(pq)], t if t.strip() else ti) for i, (ti, t) in enumerate(pp)]
+        assert np.asarray(tokenize_2_11(tok, None, pairs, 40)["input_ids"]).tolist() == g["probe_hop2"]
+        ids, _ = encode_pairs_2_11(tok, [unicodedata.normalize("NFD", ti.strip()) for ti, t in pp], [(t.strip() or ti) for ti, t in pp], 30, False)
+        assert [list(r) for r in ids] == g["probe_ctx"]
 
 
 def test_light_tokenizer_is_the_hf_tokenizer_without_transformers(tmp_path, tiny_roberta_tokenizer):
