@@ -658,14 +658,19 @@ def cli_mode(args):
     outs = {}
     try:
         import subprocess
-        for name in [x for x in args.cli_legs.split(",") if x]:
+        for leg_i, name in enumerate(x for x in args.cli_legs.split(",") if x):
             save = os.path.join(out_dir, f"paths_{name}.jsonl")
             stats = os.path.join(out_dir, f"stats_{name}")
             # a FRESH process per leg, as a user starts the drop-in script (this process has long touched the device: the CLI's worker processes must
             # be forked before that); scripts/gpu_cli_multirank.py = eval_mhop_retrieval.main(argv) + its counters (LAST_RUN) left in a file
             t0 = time.perf_counter()
+            env = dict(os.environ)
+            if world > 1 and env.get("MASTER_PORT", "").isdigit():
+                # every leg's ranks rendezvous on their OWN port, derived the same way on every rank (the legs used to reuse the launcher's
+                # port one after another with no settling time between them)
+                env["MASTER_PORT"] = str(1024 + (int(env["MASTER_PORT"]) - 1024 + 101 * (leg_i + 1)) % (65535 - 1024))
             rcp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_cli_multirank.py"), stats] + base + ["--save-path", save] + legs[name],
-                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
             wall = time.perf_counter() - t0
             if rcp.returncode != 0:
                 raise SystemExit(f"CLI leg {name} failed:\n{rcp.stderr[-3000:]}")
@@ -710,7 +715,9 @@ def self_launch(args):
     if args.mode in ("encode-corpus", "structured"):
         return
     env_world = os.environ.get("WORLD_SIZE")
-    if env_world is not None:
+    under_launcher = env_world is not None and ("RANK" in os.environ or "LOCAL_RANK" in os.environ)
+    if env_world is not None and not (int(env_world) == 1 and args.gpus > 1 and not under_launcher):
+        # (an environment that merely EXPORTS WORLD_SIZE=1, with no launcher around this process, falls through to the self-launch below: ADVICE r5)
         if int(env_world) != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks; refusing to print a line whose n_gpus is not --gpus")
         return
@@ -729,6 +736,8 @@ def self_launch(args):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print("bench.py: self-launching " + " ".join(cmd), file=sys.stderr, flush=True)
     env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)  # the launcher sets its own
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // args.gpus)))
     os.execvpe(sys.executable, cmd, env)

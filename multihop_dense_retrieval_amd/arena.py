@@ -25,7 +25,11 @@ def arena_tag(tokenizer, roberta, max_tokens):
         vocab = hashlib.sha256(json.dumps(sorted(tokenizer.get_vocab().items())).encode()).hexdigest()[:16]
     except Exception:
         vocab = "unknown"
-    return (f"arena-v2|prefix_space_2_11={int(PREFIX_SPACE_2_11 and is_roberta_family(tokenizer))}|tokenizer={tokenizer.__class__.__name__}|vocab={vocab}"
+    # (the class NAME without a trailing "Fast": the light loader takes it from tokenizer_config.json, AutoTokenizer of transformers 4 appends "Fast" for the same
+    #  files, transformers 5 does not -- same BPE, same ids, one tag: ADVICE r5)
+    name = tokenizer.__class__.__name__
+    name = name[:-4] if name.endswith("Fast") else name
+    return (f"arena-v2|prefix_space_2_11={int(PREFIX_SPACE_2_11 and is_roberta_family(tokenizer))}|tokenizer={name}|vocab={vocab}"
             f"|empty_text_to_title={int(bool(roberta))}|max_tokens={max_tokens}")
 
 

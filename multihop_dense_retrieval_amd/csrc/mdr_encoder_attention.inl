@@ -213,8 +213,8 @@ attention_stream_kernel(const _Float16* __restrict__ qkv, const int* __restrict_
 
     // DMA plan: wave-instruction i covers LDS slots 64 i .. 64 i + 63 = rows 8 i .. 8 i + 7; this lane: row 8 i + (lane >> 3),
     // slot lane & 7 holding source chunk (lane & 7) ^ (row & 7) = (lane & 7) ^ (lane >> 3)
-    const int st_row = lane >> 3;
-    const int st_col = ((lane & 7) ^ st_row) * 8;
+    int st_row = lane >> 3;
+    int st_col = ((lane & 7) ^ st_row) * 8;
     // reader offsets
     const int k_rd = lr * 128;                       // + t * 2048 + (((ds * 4 + g) ^ (lr & 7)) << 4)
     const int ksw0 = ((0 * 4 + g) ^ (lr & 7)) << 4, ksw1 = ((1 * 4 + g) ^ (lr & 7)) << 4;
@@ -400,6 +400,9 @@ attention_stream_kernel(const _Float16* __restrict__ qkv, const int* __restrict_
 #ifndef MDR_ATTN_SORT  // 1: product -- the ring kernel walks the sequences longest first. 0 (measurement): in batch order
 #define MDR_ATTN_SORT 1
 #endif
+#ifndef MDR_ATTN_RESIDENT  // 1 (measurement build, round 6): sequences of at most 192 keys are served by one workgroup over ring-resident K / V
+#define MDR_ATTN_RESIDENT 0
+#endif
 #ifndef MDR_ATTN_RING_QLDS
 #define MDR_ATTN_RING_QLDS 0
 #endif
@@ -454,11 +457,21 @@ attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ 
     }
     MDR_ATTN_STAMP(0);
 #endif
-    const int start = __builtin_amdgcn_readfirstlane(cu[b]), len = __builtin_amdgcn_readfirstlane(cu[b + 1]) - start;
-    const int qb0 = blk_z * 128;
-    if (qb0 >= len) return;
+    int start = __builtin_amdgcn_readfirstlane(cu[b]), len = __builtin_amdgcn_readfirstlane(cu[b + 1]) - start;
+    int nh = (len + HK - 1) / HK;
+#if MDR_ATTN_RESIDENT
+    // Round 6 experiment: a sequence whose K and V fit the ring (nh <= NS jobs: at most 192 keys with two slots of 96) is served by ONE
+    // workgroup -- both jobs staged once, in the prologue, and every query block of the sequence computed against the resident images without another wait
+    // or barrier; the workgroups of its other query blocks leave at once. Longer sequences: the ring as before.
+    const bool resident = NS == 2 && nh <= NS && len > 128;
+    if (resident && blk_z > 0) return;
+    const int n_qblk = resident ? (len + 127) >> 7 : 1;
+#else
+    constexpr bool resident = false;
+    constexpr int n_qblk = 1;
+#endif
+    if (blk_z * 128 >= len) return;
     const int H3 = 3 * H;
-    const int nh = (len + HK - 1) / HK;
 #if MDR_ATTN_ABL == 9
     if (tid == 0 && wg_lin < kAttnStampWgs) {
         unsigned hw, xcc;
@@ -472,13 +485,13 @@ attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ 
 
     // DMA plan: wave-instruction i covers LDS slots 64 i .. 64 i + 63 = rows 8 i .. 8 i + 7; this lane: row 8 i + (lane >> 3),
     // 16-byte slot lane & 7 holding source chunk (lane & 7) ^ (row & 7) = (lane & 7) ^ (lane >> 3)
-    const int st_row = lane >> 3;
-    const int st_col = ((lane & 7) ^ st_row) * 8;
+    int st_row = lane >> 3;
+    int st_col = ((lane & 7) ^ st_row) * 8;
     // fragment readers (LDS byte addresses inside ring slot 0; images 128-byte aligned): K / Q row lr of a 16-row tile, 16-byte slot (4 ds + g) ^ (lr & 7)
     // (ds = 1: bit 6 flipped); V: this lane's 8-byte piece for d-tile 0 of pair-tile 0 (d-tile dt: ^ 32 dt)
-    const unsigned k_lds0 = lr * 128 + ((g ^ (lr & 7)) << 4);
+    unsigned k_lds0 = lr * 128 + ((g ^ (lr & 7)) << 4);
     const int vkey = 4 * g + (lr >> 2);
-    const unsigned v_lds0 = HK * 128 + vkey * 128 + (((((lr & 3) >> 1)) ^ (vkey & 7)) << 4) + (lr & 1) * 8;
+    unsigned v_lds0 = HK * 128 + vkey * 128 + (((((lr & 3) >> 1)) ^ (vkey & 7)) << 4) + (lr & 1) * 8;
 
     auto pieces_of = [&](int job) __attribute__((always_inline)) { return ((min(HK, len - job * HK) + 31) >> 5) * 4; };  // wave-instructions per image (4 per pair-tile)
     auto stage = [&](int job, int slot) __attribute__((always_inline)) {  // whole pair-tiles of 32 keys, rows past the sequence clamped to its last row
@@ -499,11 +512,18 @@ attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ 
     };
     auto barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
+#pragma nounroll
+    for (int qblk = 0; qblk < n_qblk; ++qblk) {
+    const int qb0 = __builtin_amdgcn_readfirstlane((resident ? qblk : blk_z) * 128);
+#if MDR_ATTN_RESIDENT  // nothing derived from these may be hoisted out of the query-block loop (hipcc's LICM spilled 31 VGPRs and tripled the SGPRs)
+    asm volatile("" : "+s"(len), "+s"(start), "+s"(nh), "+v"(st_row), "+v"(st_col), "+v"(k_lds0), "+v"(v_lds0));
+#endif
     // ---- prologue: this wave's Q fragments (plain register loads) and job 0 (three slots: and job 1) travel together; one wait, and a compiler-visible
     // use of the Q registers right behind it -- hipcc retires a register load in front of its first use with vmcnt(0), which must not fall behind the next
     // job's DMA (MDR_ATTN_RING_QLDS=1 builds: Q through the ring's last slot instead, two more barriers)
     half8 qf[2];
 #if MDR_ATTN_RING_QLDS
+    static_assert(!MDR_ATTN_RESIDENT, "the resident experiment loads Q through registers");
     {
         const _Float16* qbase = qkv + (size_t)start * H3 + h * 64;
 #pragma unroll
@@ -527,10 +547,14 @@ attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ 
         qf[0] = *(const half8*)qsrc;
         qf[1] = *(const half8*)(qsrc + 32);
     }
-    stage(0, 0);
-    if (NS == 3 && nh > 1) stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]) : : "memory");
-    barrier();
+    if (qblk == 0) {
+        stage(0, 0);
+        if ((NS == 3 || resident) && nh > 1) stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]) : : "memory");
+        barrier();
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]) : : "memory");
+    }
 #endif
     MDR_ATTN_STAMP(1);
 
@@ -544,7 +568,7 @@ attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ 
 
     int slot = 0;
     for (int job = 0; job < nh; ++job) {
-        if (job > 0) {
+        if (job > 0 && !resident) {
 #if MDR_ATTN_ABL == 9
             if (job == 1) MDR_ATTN_STAMP(2);
             const long long t_top = wall_clock64();
@@ -557,7 +581,7 @@ attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ 
             t_wait += wall_clock64() - t_top;
 #endif
         }
-        if (job + NS - 1 < nh) stage(job + NS - 1, slot == 0 ? NS - 1 : slot - 1);
+        if (!resident && job + NS - 1 < nh) stage(job + NS - 1, slot == 0 ? NS - 1 : slot - 1);
         if (wave_valid) {
             const unsigned kb = k_lds0 + slot * SLOT, vb = v_lds0 + slot * SLOT;
             const int kc0 = job * HK;
@@ -653,6 +677,7 @@ attention_ring_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ 
                 *(half4*)(ctx + (size_t)(start + qi) * H + h * 64 + dt * 16 + 4 * g) = w;
             }
         }
+    }
     }
 #if MDR_ATTN_ABL == 9
     if (nh == 1) MDR_ATTN_STAMP(2);

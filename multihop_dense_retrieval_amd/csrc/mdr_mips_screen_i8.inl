@@ -631,10 +631,16 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
 #pragma unroll
         for (int j = 0; j < 4; ++j) P[h].sr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    // CB: the 16 row terms b_r of the super-block whose epilogue is PENDING. One set serves both accumulator sets (a second one spilled: 266 VGPRs): it is read
-    // from the super-block's own LDS slot behind MFMA 9 of that super-block's chain -- after the previous super-block's epilogue (MFMAs 0-8) has used the old
-    // values, while the slot is still this stage's -- and consumed in the first MFMAs of the next chain.
+    // CB: the addends beta_q + lambda_q b_r of the 16 rows of the super-block whose epilogue is PENDING, two per register pair. One set serves both accumulator
+    // sets (a second one spilled: 266 VGPRs). Its row terms b_r are read from the super-block's own LDS slot behind MFMA 9 of that super-block's chain -- the
+    // previous super-block's epilogue (MFMAs 0-8) has used the old values by then, and the slot is still this stage's -- by inline-asm reads the chain's own
+    // counted waits cover (LDS returns in order: behind MFMA 13's wait they have landed), and turned into addends behind MFMAs 13-20, one packed FMA each, where
+    // the chain has no other VALU work. The first version did the FMA inside `bounds` (MFMAs 0-7, already the busiest steps): +0.22 ms per 256-query pass.
+    static_assert(!CB || (MDR_I8W_PF <= 4 && 2 * NKB8 >= 22), "the b_r reads issued behind MFMA 9 are covered by the chain's wait before MFMA 13 only with <= 4 reads in flight");
+    f32x2 adv[CB ? 8 : 1];
     f32x4 brs[CB ? 4 : 1];
+#pragma unroll
+    for (int j = 0; j < (CB ? 8 : 1); ++j) adv[j] = qb2;
 #pragma unroll
     for (int j = 0; j < (CB ? 4 : 1); ++j) brs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x2 u2[8];
@@ -646,7 +652,7 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
         const f32x2 f = {(float)R.acc[2 * j], (float)R.acc[2 * j + 1]};
         const f32x2 sc = {R.sr[j >> 1][2 * (j & 1)], R.sr[j >> 1][2 * (j & 1) + 1]};
         f32x2 ad = qb2;  // beta_q (+ lambda_q b_r)
-        if constexpr (CB) ad = __builtin_elementwise_fma((f32x2){brs[j >> 1][2 * (j & 1)], brs[j >> 1][2 * (j & 1) + 1]}, ql2, qb2);
+        if constexpr (CB) ad = adv[j];
         u2[j] = __builtin_elementwise_fma(__builtin_elementwise_fma(f, qt2, qa2), sc, ad);
         mu = j == 0 ? fmaxf(u2[0][0], u2[0][1]) : fmaxf(mu, fmaxf(u2[j][0], u2[j][1]));
     };
@@ -741,9 +747,16 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
                     if constexpr (MDR_I8_ABL != 2) {
                         if constexpr (sl < 8) bounds(Rp, slc);
                         else if constexpr (sl == 8) decide(Rp);
-                        else if constexpr (CB && sl == 9) {  // (in-order LDS returns: the chain's counted waits stay sufficient with these four reads in flight)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) brs[j] = *(const f32x4*)(slot + 2 * NKB8 * kFragBytes + kI8TailB + (8 * j + 4 * lh) * 4);
+                        else if constexpr (CB && sl == 9) {
+                            const unsigned ta = (unsigned)(uintptr_t)(slot + 2 * NKB8 * kFragBytes + kI8TailB + 16 * lh);
+                            asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(brs[0]) : "v"(ta));
+                            asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(brs[1]) : "v"(ta));
+                            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(brs[2]) : "v"(ta));
+                            asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(brs[3]) : "v"(ta));
+                        } else if constexpr (CB && sl >= 13 && sl < 21) {
+                            constexpr int j = sl - 13;
+                            asm volatile("" : "+v"(brs[j >> 1]));  // (the value the asm read above delivered: not to be folded with the old one)
+                            adv[j] = __builtin_elementwise_fma((f32x2){brs[j >> 1][2 * (j & 1)], brs[j >> 1][2 * (j & 1) + 1]}, ql2, qb2);
                         }
                     }
                 });

@@ -47,6 +47,7 @@ class _LightBPE:
 
     def __init__(self, path, cfg):
         import tokenizers
+        self._path, self._cfg = path, cfg
         self._tk = tokenizers.Tokenizer.from_file(path)
         self._tk.no_padding()
         self._tk.no_truncation()
@@ -73,6 +74,20 @@ class _LightBPE:
     def __len__(self):
         return self._tk.get_vocab_size()
 
+    def __reduce__(self):  # spawn-context worker processes: rebuilt from the file, under the same class name
+        return (_light_tokenizer, (self._path, self._cfg, type(self).__name__))
+
+
+_LIGHT_CLASSES = {}
+
+
+def _light_tokenizer(path, cfg, name):
+    """_LightBPE under the HF class's name (the token-arena tag and is_roberta_family look at the class NAME); one class object per name, at module level."""
+    cls = _LIGHT_CLASSES.get(name)
+    if cls is None:
+        cls = _LIGHT_CLASSES[name] = type(name, (_LightBPE,), {"__module__": __name__})
+    return cls(path, cfg)
+
 
 def load_tokenizer(model_name):
     """`AutoTokenizer.from_pretrained(args.model_name)` (eval_mhop_retrieval.py:81) for the eval CLI. A LOCAL directory that holds a `tokenizer.json` of a
@@ -85,8 +100,10 @@ def load_tokenizer(model_name):
             with open(tc) as f:
                 cfg = json.load(f)
             name = str(cfg.get("tokenizer_class", ""))
-            if "Roberta" in name:
-                return type(name, (_LightBPE,), {})(tj, cfg)
+            #  AutoTokenizer rewrites the backend's pre-tokenizer when the config sets add_prefix_space: leave such a tokenizer to transformers.
+            # (The class name is the config's; arena_tag drops a trailing "Fast", so both loaders of any transformers version give one tag.)
+            if "Roberta" in name and not cfg.get("add_prefix_space", False):
+                return _light_tokenizer(tj, cfg, name)
         except (OSError, ValueError, ImportError):
             pass
     from transformers import AutoTokenizer

@@ -139,10 +139,13 @@ class _failure_marker:
         return False
 
 
-def wait_for_file(ready, target, what, timeout=None, poll=0.2, beat=30.0):
+def wait_for_file(ready, target, what, timeout=None, poll=0.2, beat=30.0, ok_marker=None, ok_grace=60.0, why=None):
     """Ranks other than 0: poll until `ready()`; a heartbeat line every `beat` seconds, RuntimeError when rank 0 left `<target>.failed` or after
     `timeout` seconds (MDR_SHARED_FILE_TIMEOUT, default 6 h -- tokenising / indexing a 5 M-passage corpus takes minutes, never hours). A file, not a
-    collective: a pending RCCL collective is aborted by the process-group watchdog after its own timeout (10 min by default)."""
+    collective: a pending RCCL collective is aborted by the process-group watchdog after its own timeout (10 min by default).
+    `ok_marker`: a file rank 0 touches when ITS copy of the target is valid and it is NOT building. If that marker is this job's and `ready()` still
+    fails `ok_grace` seconds later, nobody is going to write the file this rank is waiting for (a cache that is not on a shared filesystem, a transient read
+    error): RuntimeError with `why()` (the last load error) instead of a 6-hour wait."""
     import time
     timeout = float(os.environ.get("MDR_SHARED_FILE_TIMEOUT", 6 * 3600)) if timeout is None else timeout
     t0 = last = time.monotonic()
@@ -151,10 +154,16 @@ def wait_for_file(ready, target, what, timeout=None, poll=0.2, beat=30.0):
         born = psutil.Process().create_time() - 1.0
     except Exception:
         born = time.time() - 1.0
+    ok_seen = None
     while not ready():
         now = time.monotonic()
         if os.path.exists(target + ".failed") and os.path.getmtime(target + ".failed") >= born:
             raise RuntimeError(f"rank 0 failed to build {what} ({target}): {open(target + '.failed').read().strip()}")
+        if ok_marker and os.path.exists(ok_marker) and os.path.getmtime(ok_marker) >= born:
+            ok_seen = now if ok_seen is None else ok_seen
+            if now - ok_seen > ok_grace:
+                raise RuntimeError(f"rank 0 holds a valid copy of {what} and is not rebuilding it, but this rank cannot load {target}"
+                                   f"{': ' + str(why()) if why else ''} (is the cache on a filesystem every rank sees?)")
         if now - t0 > timeout:
             raise RuntimeError(f"gave up waiting for {what} ({target}) after {timeout:.0f} s: is rank 0 alive?")
         if now - last >= beat:
@@ -360,10 +369,15 @@ def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, be
         from .arena import TokenArena, arena_tag
         cache = args.corpus_dict + ".arena.npz"
         tag = arena_tag(tokenizer, roberta, args.max_q_sp_len)
+        load_err = [None]
+
         def load_arena():
             try:
                 return TokenArena.load(cache, expect_tag=tag) if os.path.exists(cache) else None  # None: written under another tokenisation rule
-            except (OSError, ValueError, EOFError):
+            except (OSError, ValueError, EOFError) as e:
+                if repr(e) != load_err[0]:
+                    logger.warning(f"token arena {cache} could not be loaded ({e!r}): treated as stale")
+                load_err[0] = repr(e)
                 return None
 
         arena = load_arena()
@@ -374,13 +388,19 @@ def _run_on_device(args, tokenizer, pool, finish_pool, world, rank, ds_items, be
             with _failure_marker(cache):
                 arena = TokenArena.from_corpus(id2doc, tokenizer, roberta=roberta, max_tokens=args.max_q_sp_len)
                 arena.save(cache, tag=tag)
+        elif rank == 0 and world > 1:
+            try:  # "my copy is valid, I am not building": lets a rank that cannot load the file give up after a minute instead of polling for hours
+                with open(cache + ".ok", "w") as f:
+                    f.write(tag if isinstance(tag, str) else repr(tag))
+            except OSError:
+                pass
         elif arena is None:
             box = {}
 
             def ready():
                 box["a"] = load_arena()
                 return box["a"] is not None
-            wait_for_file(ready, cache, "the token arena", poll=1.0)
+            wait_for_file(ready, cache, "the token arena", poll=1.0, ok_marker=cache + ".ok", why=lambda: load_err[0])
             arena = box["a"]
         arena = arena.to(torch.device("cuda"))
 
