@@ -108,13 +108,14 @@ def test_cli_chains_against_the_reference_scripts_run(golden, assets, tmp_path, 
             worst = max(worst, kth - s)
     print(f"case {ci} beam {beam} topk {topk}: best chain equal {top_equal}/{NQ}, all chains equal {all_equal}/{NQ}, JSONL lines byte-equal {n_equal}, "
           f"chain positions equal {pos_equal / NQ:.3f}, chain-set overlap {overlap / NQ:.3f}, worst captured-score deficit of a returned chain {worst:.3e}")
-    # measured (round 5, profiles/r05_cli_reference_parity.txt): 23 / 22 / 23 of 23 records byte-equal at beam 1 / 3 / 5; at beam 50 x topk 50 (2 500 paths per
-    # question, path scores ~1e2, neighbours ~1e-2 apart) every best chain equal, no question with all 50 chains in the same order
-    assert top_equal >= NQ - 2 and worst <= 0.25
+    # measured (round 6, profiles/r06_cli_reference_parity.txt; equality up to exact ties of the captured scores): best chain 23 / 23 in every case (5 / 5 in the
+    # 100 x 100 one), all chains 23 / 22 / 23 / 23 of 23 at beam 1 / 3 / 5 / 1 (12 layers); at 50 x 50 and 100 x 100 (2 500 / 10 000 paths per question, path scores
+    # ~1e2, neighbours ~1e-2 apart) chain positions equal 0.955 / 0.918, chain-set overlap 0.994 / 0.998. Bars = measured - 1.
+    assert top_equal >= NQ - 1 and worst <= 0.1
     if beam <= 5:
-        assert all_equal >= 20
+        assert all_equal >= NQ - 2
     else:
-        assert overlap / NQ >= 0.95 and pos_equal / NQ >= 0.6  # measured 0.997 / 0.820 at 50 x 50
+        assert overlap / NQ >= 0.98 and pos_equal / NQ >= 0.88
     # the log lines are the reference's, value for value when every chain agrees
     for needle in case["log"][:6]:
         assert needle in err, needle
@@ -136,7 +137,7 @@ def test_cli_only_eval_ans_against_the_reference_scripts_run(golden, assets, tmp
     assert [m["question"] for m in metrics] == [m["question"] for m in case["metrics"]]
     agree = sum(a == b for a, b in zip(metrics, case["metrics"]))
     print(f"--only-eval-ans: {agree}/17 ans_recall values equal to the script's")
-    assert agree >= 15
+    assert agree >= 16  # measured: 17 of 17
     assert "Evaluating 17 samples..." in err and "Ans Recall: " in err
     if agree == 17:
         tail = case["log"][case["log"].index("Evaluating 17 samples..."):]
@@ -161,7 +162,7 @@ def test_fever_cli_chains_against_the_reference_fever_scripts_run(golden, assets
     r0 = json.loads(got[0])
     assert list(r0.keys()) == ["id", "claim", "candidate_chains"] and len(r0["candidate_chains"]) == case["topk"] and r0["id"] == 1000
     print(f"fever case {fi} beam {case['beam1']} x {case['beam2']} topk {case['topk']}: records byte-equal {equal}/23, best chain equal {top_equal}/23")
-    assert top_equal >= 21 and equal >= 19
+    assert top_equal >= 22 and equal >= 21  # measured (round 6): 23 / 23 and 23 / 22 of 23
 
 
 def test_encode_corpus_cli_against_the_reference_encode_corpus_scripts_run(golden, assets, tmp_path, capsys):
@@ -207,7 +208,7 @@ def test_encode_corpus_cli_other_input_branches_against_the_reference_scripts_ru
     err = np.abs(emb[:len(want)] - want)
     cos = (emb[:len(want)] * want).sum(1) / (np.linalg.norm(emb[:len(want)], axis=1) * np.linalg.norm(want, axis=1))
     print(f"encode_corpus [{name}] vs the reference script's fp32 run: max |d| {err.max():.3e}; min cosine {cos.min():.6f}")
-    assert err.max() <= 1.5e-2 and cos.min() >= 0.99999
+    assert err.max() <= 8e-3 and cos.min() >= 0.99999  # measured: 3.2e-3 - 3.4e-3
     for ln in v["stdout"]:
         assert ln.replace("<assets>", os.path.dirname(assets[key])) in out, ln
 
