@@ -669,6 +669,9 @@ def cli_mode(args):
                 # every leg's ranks rendezvous on their OWN port, derived the same way on every rank (the legs used to reuse the launcher's
                 # port one after another with no settling time between them)
                 env["MASTER_PORT"] = str(1024 + (int(env["MASTER_PORT"]) - 1024 + 101 * (leg_i + 1)) % (65535 - 1024))
+                # under torchrun the children would otherwise be CLIENTS of the launcher agent's store at the launcher's port (TORCHELASTIC_USE_AGENT_STORE): nobody
+                # listens on the derived port and the rendezvous hangs (round 6, first version: the 2-rank leg sat in its 900 s timeout); rank 0 of each leg hosts its own
+                env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
             rcp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_cli_multirank.py"), stats] + base + ["--save-path", save] + legs[name],
                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
             wall = time.perf_counter() - t0
