@@ -223,9 +223,10 @@ int mdr_upload_host(void* dst_dev, const void* src_host, size_t bytes, int devic
 int mdr_test_gemm_f16(const void* A_dev, const void* W_dev, const float* bias_dev, int M, const int* m_dev, int N, int K,
                       void* out_dev, int epilogue, int kernel, int device, void* stream);
 /* Measurement hooks that exist only in VARIANT builds of these sources (never in the product library) are declared in
- * include/mdr_hip_measure.h. No environment variable changes what any entry point above computes: MDR_GEMM_CFG, MDR_MIPS_WIDE and
- * MDR_MIPS_I8 only choose between kernels that return the same bits / the same exact results (tests/test_capi_symbols.py keeps
- * the list of getenv() names in csrc/ closed). */
+ * include/mdr_hip_measure.h. No environment variable changes what any entry point above computes: MDR_GEMM_CFG, MDR_MIPS_WIDE,
+ * MDR_MIPS_I8, MDR_MIPS_I8_CB (the int8 tier's query split forced on / off) and MDR_MIPS_EVEN_GROUPS (how the passes of a > 256-query
+ * call share the queries) only choose between kernels / schedules that return the same bits / the same exact results
+ * (tests/test_capi_symbols.py keeps the list of getenv() names in csrc/ closed). */
 
 #ifdef __cplusplus
 }

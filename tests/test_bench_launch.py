@@ -30,10 +30,35 @@ def test_one_gpu_and_launched_runs_do_not_exec(monkeypatch, no_launcher):
 
 
 def test_world_size_mismatch_is_an_error(monkeypatch, no_launcher):
+    """A LAUNCHER (RANK / LOCAL_RANK set) that started another number of ranks than --gpus: refuse to print a line whose n_gpus is not --gpus."""
     monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
     with pytest.raises(SystemExit) as e:
         bench.self_launch(_args(gpus=8))
     assert "WORLD_SIZE=1" in str(e.value)
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.delenv("RANK")
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(_args(gpus=8))
+    assert "WORLD_SIZE=4" in str(e.value)
+
+
+def test_an_exported_world_size_of_one_without_a_launcher_self_launches(monkeypatch, no_launcher):
+    """an environment that merely exports WORLD_SIZE=1 (no RANK / LOCAL_RANK: no launcher around this process) used to abort `--gpus 8`; it now starts
+    the 8 ranks itself, with the stale variables removed from the launcher's environment."""
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    seen = {}
+
+    def fake_exec(exe, cmd, env):
+        seen.update(cmd=cmd, env=env)
+        raise SystemExit(0)
+    monkeypatch.setattr(os, "execvpe", fake_exec)
+    with pytest.raises(SystemExit):
+        bench.self_launch(_args(gpus=8))
+    assert seen["cmd"][seen["cmd"].index("--nproc-per-node") + 1] == "8" and "WORLD_SIZE" not in seen["env"]
 
 
 def test_execs_torch_distributed_run_with_n_ranks(monkeypatch, no_launcher):

@@ -50,8 +50,9 @@ def test_product_library_holds_no_measurement_code():
     for knob in (b"MDR_GEMM_ABL", b"MDR_GEMM_EPI", b"MDR_I8_ABL", b"MDR_ATTN_ABL", b"g_gemm_stamp", b"g_i8_stamp", b"g_attn_stamp", b"g_stream_cus", b"mips_gemmk_kernel"):
         assert knob not in blob, f"{knob!r} found in the product library"
     # (MDR_UPLOAD_THREADS: memcpy threads of the host-upload pipeline; MDR_MIPS_EVEN_GROUPS: how the passes of a > 256-query call share the queries;
-    #  MDR_MIPS_GEMMK is read by -DMDR_MIPS_GEMMK=1 measurement builds only)
-    allowed = {"MDR_GEMM_CFG", "MDR_MIPS_WIDE", "MDR_MIPS_I8", "MDR_MIPS_GEMMK", "MDR_UPLOAD_THREADS", "MDR_MIPS_EVEN_GROUPS"}
+    #  MDR_MIPS_I8_CB: forces the int8 tier's query split on / off -- any lambda is correct, same ids and scores; MDR_MIPS_GEMMK is read by -DMDR_MIPS_GEMMK=1
+    #  measurement builds only)
+    allowed = {"MDR_GEMM_CFG", "MDR_MIPS_WIDE", "MDR_MIPS_I8", "MDR_MIPS_GEMMK", "MDR_UPLOAD_THREADS", "MDR_MIPS_EVEN_GROUPS", "MDR_MIPS_I8_CB"}
     seen = set()
     for src in glob.glob(os.path.join(ROOT, "multihop_dense_retrieval_amd", "csrc", "*")):
         seen |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(src).read()))
