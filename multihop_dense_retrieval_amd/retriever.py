@@ -257,8 +257,7 @@ class _HipRobertaEncoder:
                 torch.cuda.synchronize(self.device)
                 graph = torch.cuda.CUDAGraph()
                 ls = self.lane_stream(lane)  # a lane bound to its own stream is captured ON it
-                mode = getattr(self, "capture_error_mode", "global")  # "thread_local" while another thread of the process talks to the device (the CLI's index upload)
-                with (torch.cuda.graph(graph, stream=ls, capture_error_mode=mode) if ls is not None else torch.cuda.graph(graph, capture_error_mode=mode)):
+                with (torch.cuda.graph(graph, stream=ls) if ls is not None else torch.cuda.graph(graph)):
                     self._forward_into(sid, smk, sout, lane)
             finally:
                 _lib.check(_lib.lib().mdr_encoder_set_fill_hint(self._h, 0.0))
