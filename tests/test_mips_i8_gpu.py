@@ -247,3 +247,33 @@ def test_query_split_on_rows_with_a_large_common_component(mdr, nq):
     iid.add(torch.randn((50_000, D_), generator=g, device="cuda"))
     iid.search(noise.contiguous(), 1)
     assert not iid.telemetry(nq, 1)["i8_query_split"]
+
+
+def test_query_split_on_the_hip_encoders_own_outputs(mdr):
+    """Rows = this repo's RobertaCtxEncoder outputs for 150 k synthetic passages (random-init roberta-base geometry: a shared LayerNorm bias, nearly collapsed rows --
+    the corpus of bench.py's `structured.encoder_geometry`, scripts/structured_corpora.py), queries from the same encoder. The index switches the query split on,
+    the int8 tier alone decides, and every id / score is the exact kernel's (round 5's code handed such a corpus over to the slower tiers at 5 M rows)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import structured_corpora as sc
+    from multihop_dense_retrieval_amd.retriever import RobertaCtxEncoder
+    dev = torch.device("cuda")
+    model = RobertaCtxEncoder.random_init(device=dev, seed=3)
+    idx = mdr.IndexFlatIP(D_)
+    n = 150_000
+    idx.reserve(n)
+    first = None
+    for _, x in sc.encoder_rows(model, n, 8, 24, dev):
+        first = x[:50_000].clone() if first is None else first
+        idx.add(x)
+    assert idx.ntotal == n
+    c = first.mean(0)
+    assert float(c.norm()) > 2.0 * float((first - c).norm(dim=1).mean())  # the geometry the split is for: the common component dominates
+    for nq in (100, 200):
+        q = sc.encoder_queries(model, nq, 8, 24, dev)
+        t = check(idx, q, expect_i8_decides=True)
+        idx.search(q, 1)
+        t = idx.telemetry(nq, 1)
+        assert t["i8_query_split"] and t["i8_tier"] and not t["i8_overflow"] and t["fallback"] == 0, t
+        print(f"encoder-geometry rows, nq {nq}: candidates emitted {t['candidates']}, re-scored {t['i8_refined']}")
