@@ -267,6 +267,37 @@ def _search_case(idx, q, chunks, dup_ok=False):
             "returned_score_vs_bruteforce_maxabs": round(float((D[:, 0] - got).abs().max()), 6)}
 
 
+def _search_case_k(idx, q, chunks, k):
+    """A beam > 1 search shape on a structured corpus (the reference's default --beam-size 5 / BASELINE configs[3]'s beam 4): ms per call, whether the screen decided, and
+    the returned lists against a brute-force fp32 matmul over all rows (same noise rule as verify_full_size: a differing id is fine inside 2e-3 of score)."""
+    nq = q.shape[0]
+    D, I = idx.search_device(q, k)
+    torch.cuda.synchronize()
+    t = idx.telemetry(nq, k)
+    for _ in range(2):
+        idx.search_device(q, k)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        idx.search_device(q, k)
+    e1.record()
+    torch.cuda.synchronize()
+    run_s = torch.full((nq, k), -float("inf"), device=q.device)
+    run_i = torch.full((nq, k), -1, dtype=torch.int64, device=q.device)
+    row0 = 0
+    for x in chunks:
+        s, i = torch.topk(q @ x.T, k, dim=1)
+        cat_s, cat_i = torch.cat([run_s, s], 1), torch.cat([run_i, i + row0], 1)
+        run_s, o = torch.topk(cat_s, k, dim=1)
+        run_i = torch.gather(cat_i, 1, o)
+        row0 += x.shape[0]
+    differ = run_i != I
+    ok = bool(((run_s - D).abs()[differ] <= 2e-3).all()) and float((run_s[:, k - 1] - D[:, k - 1]).max()) <= 2e-3
+    return {"ms_per_search": round(e0.elapsed_time(e1) / 5, 4), "kernel": idx.last_kernel(), "exact_fallback_ran": bool(t["fallback"]),
+            "candidates_per_query": round(t["candidates"] / nq, 1), "id_agreement_with_bruteforce": round(float((~differ).float().mean()), 4),
+            "lists_equal_up_to_matmul_noise": ok}
+
+
 def anisotropic_subresult(args, device):
     """The MIPS of the headline (5M x 768, beam 1, 100 / 200 queries per call) on ANISOTROPIC rows -- m u + N(0, 1) for a fixed unit
     vector u, m = args.aniso_m (dense-retrieval embeddings share a large common component; iid rows are the easy case for any
@@ -335,6 +366,8 @@ def structured_subresult(args, device):
         for nq in (100, 200):
             q, _ = sc.clustered_queries(centres, chunks[0], nq, device)
             res[f"nq{nq}"] = _search_case(idx, q, chunks)
+        q, _ = sc.clustered_queries(centres, chunks[0], 400, device)
+        res["k4_nq400"] = _search_case_k(idx, q, chunks, 4)
         out["clustered"] = res
         del idx, chunks, centres
         torch.cuda.empty_cache()
@@ -358,6 +391,7 @@ def structured_subresult(args, device):
         for nq in (100, 200):
             q = sc.encoder_queries(model, nq, lo, hi, device)
             res[f"nq{nq}"] = _search_case(idx, q, chunks)
+        res["k4_nq400"] = _search_case_k(idx, sc.encoder_queries(model, 400, lo, hi, device), chunks, 4)
         out["encoder_geometry"] = res
         del idx, chunks, model
         torch.cuda.empty_cache()
