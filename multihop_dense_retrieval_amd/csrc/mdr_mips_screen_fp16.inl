@@ -612,6 +612,9 @@ mips_screenk_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, co
 // ---- the screen-k kernel with 32 queries per wave (256 per pass): see mips_screen32_kernel for the tile and mips_screenk_kernel
 // for the list protocol. Two lanes (l, l + 32) share a query; a stage's appends are issued at once (the one-ballot fast path makes
 // stages with a hit the exception, so the stores rarely sit between the DMA batches of the counted vmcnt wait).
+#ifndef MDR_SK32_ABL
+#define MDR_SK32_ABL 0  // measurement builds (WRONG results): 1 = no DMA behind the prologue (compute on stale LDS), 2 = DMA only (no MFMA chain, no lists)
+#endif
 template <int NKB, bool BF>
 __global__ void __launch_bounds__(512, 2)
 mips_screenk32_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, const char* __restrict__ Qhi, const float* __restrict__ qbound,
@@ -658,14 +661,15 @@ mips_screenk32_kernel(const char* __restrict__ Xhi, long long n_rows, int n_sb, 
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + 2 < n_it) issue_super_block<NKB>(Xhi, b + (it + 2) * G, lds + ((it + 2) % 3) * SB_BYTES, wave, lane);
-        if (!wave_active) continue;
+        if (it + 2 < n_it && MDR_SK32_ABL != 1) issue_super_block<NKB>(Xhi, b + (it + 2) * G, lds + ((it + 2) % 3) * SB_BYTES, wave, lane);
+        if (!wave_active || MDR_SK32_ABL == 2) continue;
 
-        const char* p = lds + (it % 3) * SB_BYTES + rd_off;
+        const char* p = lds + (MDR_SK32_ABL == 1 ? (it & 1) : (it % 3)) * SB_BYTES + rd_off;
         const f32x16 acc = mfma_chain32<NKB, BF>(p, qf);
         float m16 = acc[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) m16 = fmaxf(m16, acc[r]);
+        if (MDR_SK32_ABL) { asm volatile("" : "+v"(m16)); continue; }
         if (__ballot(q_valid && m16 >= tau) == 0ull) continue;  // nothing of this super-block can enter any list (tau = +inf for padding lanes)
         const unsigned row0 = (unsigned)(b + it * G) * 32u + 4u * (unsigned)lh;
 #pragma unroll
