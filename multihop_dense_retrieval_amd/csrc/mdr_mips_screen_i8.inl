@@ -502,6 +502,9 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 // `fill(sl)` is called behind MFMA sl and pinned there: the caller's VALU work (the epilogue of the PREVIOUS super-block) issues in
 // the shadow of the 32-cycle MFMAs instead of after the chain.
+#ifndef MDR_I8W_PIN
+#define MDR_I8W_PIN 1  // 1 (product since round 6): pin every `bounds` slice of the wide kernel behind its MFMA; 0 (measurement): let hipcc sink them into `decide`
+#endif
 #ifndef MDR_I8W_PF
 #define MDR_I8W_PF 4  // fragment reads in flight ahead of the MFMA that consumes them (<= 8)
 #endif
@@ -655,6 +658,14 @@ mips_screen8w_kernel(const char* __restrict__ X8, long long n_rows, int n_sb, co
         if constexpr (CB) ad = adv[j];
         u2[j] = __builtin_elementwise_fma(__builtin_elementwise_fma(f, qt2, qa2), sc, ad);
         mu = j == 0 ? fmaxf(u2[0][0], u2[0][1]) : fmaxf(mu, fmaxf(u2[j][0], u2[j][1]));
+#if MDR_I8W_PIN
+        // Round 6: without this pin hipcc SINKS the eight `bounds` slices into `decide` (their only consumer, under `if (R.have)`): the ISA showed MFMAs 0-8 back to back and
+        // then one block of 16 conversions + 16 packed FMAs + 25 max operations between MFMA 8 and MFMA 9 -- the epilogue was inside the chain but not IN THE SHADOW of its
+        // MFMAs. An opaque use keeps slice j behind MFMA j (the sched_barrier behind every fill() only orders what is already there). Measured, same box, alternating
+        // (profiles/r06_i8w_pinned_bounds_ab.txt): main pass 982-987 -> 974 us, search stage 1.094-1.100 -> 1.076-1.084 ms, 244 instead of 234 VGPRs. Two waves per SIMD
+        // were already hiding most of the block; the gain is what they did not.
+        asm volatile("" : "+v"(u2[j]), "+v"(mu));
+#endif
     };
     auto decide = [&](Pending& R) __attribute__((always_inline)) {
         if (!R.have) return;
