@@ -65,3 +65,19 @@ def test_more_ranks_than_devices_is_refused_without_share_gpu():
     n = torch.cuda.device_count() + 1
     err = _bench(["--gpus", str(n)] + COMMON, expect_rc=1)
     assert "HIP device(s) visible" in err
+
+
+def test_structured_mode_reports_both_corpora_with_exact_ids():
+    """`bench.py --mode structured` (round 6; the same sub-results ride in every default line): the k = 1 search on a clustered corpus and on the HIP encoder's own
+    outputs, here at 300 k rows -- int8 tier deciding, query split on for the encoder rows only, ids equal to the brute force up to exact copies, and the beam > 1 case."""
+    r = _bench(["--mode", "structured", "--rows", "300000"])
+    s = r["structured"]
+    assert set(s) == {"clustered", "encoder_geometry"}
+    for name, v in s.items():
+        for nq in ("nq100", "nq200"):
+            x = v[nq]
+            assert x["int8_tier_decided"] and not x["exact_fallback_ran"], (name, nq, x)
+            assert x["top1_agreement_up_to_exact_ties"] == 1.0 and x["returned_score_vs_bruteforce_maxabs"] <= 5e-3, (name, nq, x)
+        assert v["k4_nq400"]["lists_equal_up_to_matmul_noise"] and not v["k4_nq400"]["exact_fallback_ran"], (name, v["k4_nq400"])
+    assert s["encoder_geometry"]["stats"]["mean_norm"] > 2 * s["encoder_geometry"]["stats"]["centred_row_norm_mean"]  # the geometry the query split is for
+    assert s["clustered"]["stats"]["mean_norm"] < 0.2 * s["clustered"]["stats"]["centred_row_norm_mean"]
