@@ -265,19 +265,27 @@ bool gemmk_on(const mdr_index* h) {
     return false;
 #endif
 }
-// Query groups of a call with more than kWideQ queries on the 32-queries-per-wave kernels (round 6). A pass of those kernels costs its active waves (32 queries each;
-// idle waves skip the MFMAs) down to the HBM floor of one plane read, so the ceil(nq / 256) passes share the ceil(nq / 32) waves EVENLY instead of 256 + 256 + ... + rest:
-// nq 300 = 160 + 140 (was 256 + 44: a full pass for 44 queries), nq 800 = 224 + 192 + 192 + 192 (was 3 x 256 + 32). Every buffer the groups index (query fragments in
-// 16-query blocks, bounds, thresholds, best, outputs) is linear in the query number, so a group is just (first query, count) with the first a multiple of 32.
-// MDR_MIPS_EVEN_GROUPS=0 restores the old cut, =2 additionally sends groups of at most 128 queries to the 16-queries-per-wave kernels (both for A/B runs).
+// Query groups of a call with more than kWideQ queries on the 32-queries-per-wave kernels (round 6). VERDICT r5 item 4 asked for the ceil(nq / 256) passes to share the
+// ceil(nq / 32) waves EVENLY instead of 256 + 256 + ... + rest (nq 300 = 160 + 140 instead of 256 + 44, nq 800 = 224 + 3 x 192 instead of 3 x 256 + 32), on the model that a pass
+// costs its active waves down to the HBM floor. Measured (profiles/r06_query_groups_ab.txt, r06_query_groups_k_sweep.txt): results bit-identical, time within +-4 % -- a pass costs
+// its HBM time PLUS a per-wave term that is the clock falling under matrix-pipe load (profiles/r06_screenk32_overlap_ablation_and_clock.txt), so moving waves between passes moves
+// little. What is left is a k-dependence: nq 800 at 6.25 M bf16 rows, even vs old cut: k 8 / 16: -2 %, k 32: equal, k 64: +2 %, k 100: +4 %; 5 M fp32-accurate rows: k 8 -2.5 %,
+// k 100 +2.5 %, k 1 +1 % (with long lists the 32-query remainder is cheapest on the 16-queries-per-wave kernels). Rule: the even cut for 2 <= k <= 32, the old cut otherwise.
+// Every buffer the groups index (query fragments in 16-query blocks, bounds, thresholds, best, outputs) is linear in the query number, so a group is just (first query, count)
+// with the first a multiple of 32. MDR_MIPS_EVEN_GROUPS: 0 = the old cut always, 1 (default) = the rule, 2 = even + groups of <= 128 queries on the 16-queries-per-wave
+// kernels, 3 = the even cut always (A/B runs and tests; same results in every mode).
 int even_groups_mode() {
     static const int m = getenv("MDR_MIPS_EVEN_GROUPS") ? atoi(getenv("MDR_MIPS_EVEN_GROUPS")) : 1;
     return m;
 }
+bool even_cut(int k) {
+    const int m = even_groups_mode();
+    return m >= 2 || (m == 1 && k >= 2 && k <= 32);
+}
 struct QGroup { int q0, n; };
 int wide_group_count(int nq) { return (nq + kWideQ - 1) / kWideQ; }
-QGroup wide_group(int nq, int gi) {
-    if (even_groups_mode() == 0) return {gi * kWideQ, nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ};
+QGroup wide_group(int nq, int gi, int k) {
+    if (!even_cut(k)) return {gi * kWideQ, nq - gi * kWideQ < kWideQ ? nq - gi * kWideQ : kWideQ};
     const int ng = wide_group_count(nq), waves = (nq + 31) / 32;
     const int base = waves / ng, extra = waves % ng;
     const int w0 = gi * base + (gi < extra ? gi : extra), w1 = w0 + base + (gi < extra ? 1 : 0);
@@ -492,7 +500,7 @@ int run_screen32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
     const int n_sb = (int)((h->ntotal + 31) / 32);
     // (gmax and sctl[0..63] are part of the search call's zero block: cleared once by mdr_index_search)
     for (int gi = 0; gi < ngroups; ++gi) {
-        const QGroup gq = wide_group(nq, gi);
+        const QGroup gq = wide_group(nq, gi, 1);
         const int nqg = gq.n;
         const char* qg = qhi + (size_t)gq.q0 * h->d * 2;
         hipLaunchKernelGGL((mips_screen32_kernel<NKB, 0, BF>), dim3(p.G), dim3(512), lds_bytes, st, (const char*)h->hi, (long long)h->ntotal, n_sb, qg,
@@ -527,7 +535,7 @@ int run_screen8w(mdr_index* h, const SearchPlan& p, char* ws, const float* q_dev
     // (gmax, gstar and ctl8 are part of the search call's zero block: cleared once by mdr_index_search)
     // (q8 / qab were written by prep_queries_both_kernel, together with the fp16 fragments: mdr_index_search)
     for (int gi = 0; gi < ngroups; ++gi) {
-        const QGroup gq = wide_group(nq, gi);
+        const QGroup gq = wide_group(nq, gi, 1);
         const int nqg = gq.n;
         const size_t g0 = (size_t)gq.q0;
         const char* qg = q8 + g0 * h->d;
@@ -621,15 +629,14 @@ int run_screenk32(mdr_index* h, const SearchPlan& p, char* ws, const float* q_de
     const int stages = sample_stages_for(k);
     MDR_HIP_TRY(hipMemsetAsync(sctl, 0, 256, st));
     for (int gi = 0; gi < ngroups; ++gi) {
-        const QGroup gq = wide_group(nq, gi);
+        const QGroup gq = wide_group(nq, gi, k);
         const int nqg = gq.n;
         const size_t g0 = (size_t)gq.q0;
         const char* qg = qhi + g0 * h->d * 2;
         const float* bg = bound + g0;
         float* tg = tau0 + g0;
-        // a group of at most 128 queries may take the 16-queries-per-wave kernels (list stride kStreamQ): always under the old cut (its remainder group), under the even
-        // cut only when asked for (mode 2) -- an even group is at least half a pass's waves, which the 32-queries-per-wave kernel serves at its HBM floor
-        const bool narrow = ngroups > 1 && nqg <= kStreamQ && (even_groups_mode() == 2 || (even_groups_mode() == 0 && gi == ngroups - 1));
+        // a group of at most 128 queries takes the 16-queries-per-wave kernels (list stride kStreamQ): under the old cut its remainder group, under the even cut only in mode 2
+        const bool narrow = ngroups > 1 && nqg <= kStreamQ && (even_groups_mode() == 2 || (!even_cut(k) && gi == ngroups - 1));
         const int qcap = narrow ? kStreamQ : kWideQ;
         MDR_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)p.G * qcap * 4, st));
         MDR_HIP_TRY(hipMemsetAsync(wgmax, 0, (size_t)p.G * stages * qcap * 4, st));
