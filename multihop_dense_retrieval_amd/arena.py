@@ -20,6 +20,7 @@ def arena_tag(tokenizer, roberta, max_tokens):
     import hashlib
     import json
 
+    from . import data as _data
     from .data import PREFIX_SPACE_2_11, is_roberta_family
     try:
         vocab = hashlib.sha256(json.dumps(sorted(tokenizer.get_vocab().items())).encode()).hexdigest()[:16]
@@ -29,7 +30,8 @@ def arena_tag(tokenizer, roberta, max_tokens):
     #  files, transformers 5 does not -- same BPE, same ids, one tag: ADVICE r5)
     name = tokenizer.__class__.__name__
     name = name[:-4] if name.endswith("Fast") else name
-    return (f"arena-v2|prefix_space_2_11={int(PREFIX_SPACE_2_11 and is_roberta_family(tokenizer))}|tokenizer={name}|vocab={vocab}"
+    rstrip = "|rstrip_segments_2_11=1" if (_data.RSTRIP_SEGMENTS_2_11 and is_roberta_family(tokenizer)) else ""  # (absent when off: caches written before the switch existed stay valid)
+    return (f"arena-v2|prefix_space_2_11={int(_data.PREFIX_SPACE_2_11 and is_roberta_family(tokenizer))}{rstrip}|tokenizer={name}|vocab={vocab}"
             f"|empty_text_to_title={int(bool(roberta))}|max_tokens={max_tokens}")
 
 

@@ -106,6 +106,22 @@ if "probe_questions" in g:  # the strings of round 6 (trailing / leading blanks,
             bad += 1
             print(f"probe passage {pp_[i]!r}: ours {list(a)} vs 2.11 {list(b)}")
 print("tokenisation parity with transformers", g["version"], "OK" if bad == 0 else f"FAILED ({bad} rows)")
+if bad:  # the two open rules are one-line switches in data.py: say which combination reproduces 2.11's ids
+    from multihop_dense_retrieval_amd import data as _d
+
+    def mismatches():
+        n = int((np.asarray(tokenize_2_11(tok, g["questions"], None, 70)["input_ids"]) != np.asarray(g["hop1"]["input_ids"])).any(1).sum())
+        pr = [(g["questions"][i], g["docs"][i]["text"] if g["docs"][i]["text"].strip() else g["docs"][i]["title"]) for i in range(200)]
+        n += int((np.asarray(tokenize_2_11(tok, None, pr, 350)["input_ids"]) != np.asarray(g["hop2"]["input_ids"])).any(1).sum())
+        if "probe_questions" in g:
+            n += sum(a != b for a, b in zip(np.asarray(tokenize_2_11(tok, g["probe_questions"], None, 70)["input_ids"]).tolist(), g["probe_hop1"]))
+        return n
+    keep = (_d.PREFIX_SPACE_2_11, _d.RSTRIP_SEGMENTS_2_11)
+    for ps in (True, False):
+        for rs in (False, True):
+            _d.PREFIX_SPACE_2_11, _d.RSTRIP_SEGMENTS_2_11 = ps, rs
+            print(f"  data.PREFIX_SPACE_2_11 = {ps}, data.RSTRIP_SEGMENTS_2_11 = {rs}: {mismatches()} rows differ from transformers {g['version']}")
+    _d.PREFIX_SPACE_2_11, _d.RSTRIP_SEGMENTS_2_11 = keep
 sys.exit(0 if bad == 0 else 1)
 PY
 else

@@ -330,3 +330,35 @@ def test_light_tokenizer_is_the_hf_tokenizer_without_transformers(tmp_path, tiny
         assert not isinstance(data.load_tokenizer(str(d)), data._LightBPE)
     finally:
         del os.environ["MDR_LIGHT_TOKENIZER"]
+
+
+def test_rstrip_segments_switch_changes_exactly_the_trailing_blank(tiny_roberta_tokenizer):
+    """data.RSTRIP_SEGMENTS_2_11 (round 6): the second thing about transformers 2.11 nobody can confirm offline -- does its `split_on_token` rstrip() every piece of the
+    text before the BPE, i.e. does the blank that the reference's "?" strip leaves ("... born ?" -> "... born ") become a lone space token or vanish? Default off (= what
+    the installed tokenizer does); on, ONLY texts with trailing white space change, by exactly their trailing space tokens; the token-arena tag follows the switch."""
+    from multihop_dense_retrieval_amd import data
+    from multihop_dense_retrieval_amd.arena import arena_tag
+    tok = tiny_roberta_tokenizer
+    qs = ["capital stadium born ", "capital stadium born", "  leading stays", "inner  blanks stay ", "tab at the end\t", ""]
+    assert data.RSTRIP_SEGMENTS_2_11 is False
+    off = data.tokenize_2_11(tok, qs, None, 24)
+    tag_off = arena_tag(tok, True, 350)
+    data.RSTRIP_SEGMENTS_2_11 = True
+    try:
+        on = data.tokenize_2_11(tok, qs, None, 24)
+        pairs_on = data.tokenize_2_11(tok, None, [("q born ", "passage text "), ("q", "p")], 24)
+        tag_on = arena_tag(tok, True, 350)
+        assert data.prefix_space_2_11("born ") == " born" and data.prefix_space_2_11("  x ") == "  x" and data.prefix_space_2_11("   ") == ""
+    finally:
+        data.RSTRIP_SEGMENTS_2_11 = False
+    pairs_off = data.tokenize_2_11(tok, None, [("q born ", "passage text "), ("q", "p")], 24)
+    ids_on, ids_off = on["input_ids"].tolist(), off["input_ids"].tolist()
+    real = lambda row: [t for t in row if t != tok.pad_token_id]  # noqa: E731
+    for i in (1, 2, 5):  # no trailing white space: untouched
+        assert ids_on[i] == ids_off[i], qs[i]
+    assert real(ids_on[0]) == real(ids_on[1]) == real(ids_off[1])  # "born " under the switch == "born"
+    for i in (0, 3, 4):
+        a, b = real(ids_on[i]), real(ids_off[i])
+        assert len(a) < len(b) and a[:-1] == b[:len(a) - 1] and a[-1] == b[-1] == tok.eos_token_id, qs[i]  # the same text minus its trailing blank tokens
+    assert pairs_on["input_ids"][1].tolist() == pairs_off["input_ids"][1].tolist() and pairs_on["input_ids"][0].tolist() != pairs_off["input_ids"][0].tolist()
+    assert tag_on != tag_off and "rstrip_segments_2_11=1" in tag_on and "rstrip" not in tag_off  # caches written before the switch existed stay valid while it is off
