@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6 experiment: the int8 main pass for > 128 queries on FOUR waves of 64 queries (mdr_mips_screen_i8q.inl, -DMDR_I8Q=1 build, MDR_MIPS_I8Q=1) against the eight-wave kernel
+# NOTE: the kernel lives in scripts/ubench/mdr_mips_screen_i8q.inl.txt now (archived after this measurement); to re-run, restore it into csrc/ with the hook in run_screen8w (git show 3016e19^) and build -DMDR_I8Q=1.
 set -u
 TAG=${1:-r06i8q}; REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 export MDR_LIB_PATH=$REPO/multihop_dense_retrieval_amd/libmdrhip_i8q.so
