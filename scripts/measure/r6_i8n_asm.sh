@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: the 16-queries-per-wave int8 kernel with hand-placed LDS reads and counted waits in its four MFMA chains (-DMDR_I8N_ASM=1) against the product (hipcc's schedule:
 # a full lgkmcnt(0) in front of nearly every MFMA). Sequential loop (100 queries per search), rocprofv3 kernel averages + un-profiled runs, alternating on one box.
-# NOTE: the -DMDR_I8N_ASM source was removed again after this measurement (neutral); the chain is described in NEGATIVE_RESULTS.md "Round 6" and can be recovered from the working tree of commit 22476fd^ (profiles/r06_i8_narrow_counted_waits_neutral.txt).
+# NOTE: the -DMDR_I8N_ASM source was removed again after this measurement (neutral); the chain is archived with re-run notes as scripts/ubench/mdr_mips_chain8x16.inl.txt.
 set -u
 TAG=${1:-r06i8n}; REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 V=$REPO/multihop_dense_retrieval_amd/libmdrhip_i8nasm.so
